@@ -1,0 +1,558 @@
+// image_io.cpp — image decode (Radiance .hdr, PNG), tonemap and PNG encode.
+//
+// The reference uses stb_image / stb_image_write for the codecs
+// (src/scene.cu:713-798, src/image.cu:104); the tonemap is its own
+// (src/image.cu:11-99). What matters for parity is the VALUE of every texel and
+// of every tonemapped byte, not the PNG bytes, so:
+//   * .hdr texels follow stb's conversion: mantissa * 2^(e-136), alpha 1,
+//     all-zero when e == 0 (stb_image.h:7150-7175), rows top to bottom;
+//   * the tonemap keeps the reference's float/double operation order;
+//   * the PNG writer emits stored (uncompressed) deflate blocks — valid PNG,
+//     different bytes than stb's encoder, same pixels.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_internal.h"
+#include "hostmath.h"
+#include "pthost.h"
+
+using namespace pth;
+
+// ---- Radiance HDR ---------------------------------------------------------------
+
+namespace {
+
+struct Cursor {
+    const uint8_t *p, *end;
+    bool eof() const { return p >= end; }
+    int get() { return p < end ? *p++ : 0; }
+};
+
+std::string hdr_line(Cursor &c) {
+    std::string s;
+    while (!c.eof()) {
+        char ch = (char)c.get();
+        if (ch == '\n') break;
+        if (s.size() < 1023) s.push_back(ch);
+    }
+    return s;
+}
+
+inline void rgbe_to_float(const uint8_t rgbe[4], float *out) {
+    if (rgbe[3] != 0) {
+        float f = ldexpf(1.0f, (int)rgbe[3] - (128 + 8));
+        out[0] = rgbe[0] * f;
+        out[1] = rgbe[1] * f;
+        out[2] = rgbe[2] * f;
+    } else {
+        out[0] = out[1] = out[2] = 0;
+    }
+    out[3] = 1;
+}
+
+} // namespace
+
+extern "C" int pth_load_hdr(const char *path, int *width, int *height, float **rgba) {
+    std::vector<uint8_t> bytes;
+    if (!read_file(path, bytes)) return set_error("unable to read image %s", path);
+    Cursor c{bytes.data(), bytes.data() + bytes.size()};
+    std::string magic = hdr_line(c);
+    if (magic != "#?RADIANCE" && magic != "#?RGBE") return set_error("%s: not a Radiance HDR file", path);
+    bool format_ok = false;
+    for (;;) {
+        std::string line = hdr_line(c);
+        if (line.empty()) break;
+        if (line == "FORMAT=32-bit_rle_rgbe") format_ok = true;
+        if (c.eof()) break;
+    }
+    if (!format_ok) return set_error("%s: unsupported HDR format", path);
+    std::string dims = hdr_line(c);
+    int w = 0, h = 0;
+    if (sscanf(dims.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0)
+        return set_error("%s: unsupported HDR data layout '%s'", path, dims.c_str());
+    if ((size_t)w * (size_t)h > (size_t)1 << 28) return set_error("%s: image too large", path);
+
+    float *out = (float *)malloc(sizeof(float) * 4 * (size_t)w * (size_t)h);
+    if (!out) return set_error("out of memory");
+    std::vector<uint8_t> scan((size_t)w * 4);
+
+    auto read_flat_from = [&](int row, int col, const uint8_t first[4], bool have_first) -> bool {
+        // remaining pixels of the image stored as plain RGBE quads
+        size_t idx = (size_t)row * (size_t)w + (size_t)col;
+        size_t total = (size_t)w * (size_t)h;
+        if (have_first) {
+            rgbe_to_float(first, out + 4 * idx);
+            idx++;
+        }
+        for (; idx < total; idx++) {
+            if (c.end - c.p < 4) return false;
+            rgbe_to_float(c.p, out + 4 * idx);
+            c.p += 4;
+        }
+        return true;
+    };
+
+    bool ok = true;
+    if (w < 8 || w >= 32768) {
+        ok = read_flat_from(0, 0, nullptr, false);
+    } else {
+        for (int j = 0; j < h && ok; j++) {
+            if (c.end - c.p < 4) {
+                ok = false;
+                break;
+            }
+            uint8_t head[4] = {c.p[0], c.p[1], c.p[2], c.p[3]};
+            c.p += 4;
+            if (head[0] != 2 || head[1] != 2 || (head[2] & 0x80)) {
+                // not run-length encoded: stb decodes the rest flat, and only
+                // accepts this on the first scanline
+                if (j != 0) {
+                    ok = false;
+                    break;
+                }
+                ok = read_flat_from(0, 0, head, true);
+                j = h;
+                break;
+            }
+            int len = (head[2] << 8) | head[3];
+            if (len != w) {
+                ok = false;
+                break;
+            }
+            for (int k = 0; k < 4 && ok; k++) {
+                int i = 0;
+                while (i < w) {
+                    if (c.eof()) {
+                        ok = false;
+                        break;
+                    }
+                    int count = c.get();
+                    if (count > 128) {
+                        count -= 128;
+                        if (count == 0 || count > w - i || c.eof()) {
+                            ok = false;
+                            break;
+                        }
+                        uint8_t value = (uint8_t)c.get();
+                        for (int z = 0; z < count; z++) scan[(size_t)(i++) * 4 + (size_t)k] = value;
+                    } else {
+                        if (count == 0 || count > w - i || c.end - c.p < count) {
+                            ok = false;
+                            break;
+                        }
+                        for (int z = 0; z < count; z++) scan[(size_t)(i++) * 4 + (size_t)k] = (uint8_t)c.get();
+                    }
+                }
+            }
+            if (!ok) break;
+            for (int i = 0; i < w; i++) rgbe_to_float(&scan[(size_t)i * 4], out + 4 * ((size_t)j * (size_t)w + (size_t)i));
+        }
+    }
+    if (!ok) {
+        free(out);
+        return set_error("%s: corrupt HDR data", path);
+    }
+    *width = w;
+    *height = h;
+    *rgba = out;
+    return 0;
+}
+
+// ---- inflate + PNG decode ---------------------------------------------------------
+
+namespace {
+
+struct BitReader {
+    const uint8_t *p, *end;
+    uint32_t acc = 0;
+    int n = 0;
+    bool fail = false;
+    uint32_t bits(int count) {
+        while (n < count) {
+            if (p >= end) {
+                fail = true;
+                return 0;
+            }
+            acc |= (uint32_t)(*p++) << n;
+            n += 8;
+        }
+        uint32_t v = count ? (acc & ((1u << count) - 1)) : 0;
+        acc >>= count;
+        n -= count;
+        return v;
+    }
+    void align() {
+        acc = 0;
+        n = 0;
+    }
+};
+
+struct Huffman {
+    uint16_t count[16];
+    uint16_t symbol[288];
+    bool build(const uint8_t *lengths, int num) {
+        memset(count, 0, sizeof(count));
+        for (int i = 0; i < num; i++) count[lengths[i]]++;
+        count[0] = 0;
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int i = 1; i < 15; i++) offs[i + 1] = (uint16_t)(offs[i] + count[i]);
+        for (int i = 0; i < num; i++)
+            if (lengths[i]) symbol[offs[lengths[i]]++] = (uint16_t)i;
+        return true;
+    }
+    int decode(BitReader &br) const {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; len++) {
+            code |= (int)br.bits(1);
+            if (br.fail) return -1;
+            int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+};
+
+bool inflate_zlib(const uint8_t *data, size_t size, std::vector<uint8_t> &out) {
+    if (size < 6) return false;
+    BitReader br{data + 2, data + size};
+    static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27,
+                                          31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129,
+                                           193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    int final_block;
+    do {
+        final_block = (int)br.bits(1);
+        int type = (int)br.bits(2);
+        if (br.fail) return false;
+        if (type == 0) {
+            br.align();
+            if (br.end - br.p < 4) return false;
+            uint16_t len = (uint16_t)(br.p[0] | (br.p[1] << 8));
+            br.p += 4;
+            if (br.end - br.p < len) return false;
+            out.insert(out.end(), br.p, br.p + len);
+            br.p += len;
+            continue;
+        }
+        Huffman lit, dist;
+        if (type == 1) {
+            uint8_t l[288];
+            for (int i = 0; i < 144; i++) l[i] = 8;
+            for (int i = 144; i < 256; i++) l[i] = 9;
+            for (int i = 256; i < 280; i++) l[i] = 7;
+            for (int i = 280; i < 288; i++) l[i] = 8;
+            lit.build(l, 288);
+            uint8_t d[30];
+            for (int i = 0; i < 30; i++) d[i] = 5;
+            dist.build(d, 30);
+        } else if (type == 2) {
+            int hlit = (int)br.bits(5) + 257, hdist = (int)br.bits(5) + 1, hclen = (int)br.bits(4) + 4;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t cl[19] = {0};
+            for (int i = 0; i < hclen; i++) cl[order[i]] = (uint8_t)br.bits(3);
+            if (br.fail || hlit > 286 || hdist > 30) return false;
+            Huffman clh;
+            clh.build(cl, 19);
+            uint8_t lengths[320] = {0};
+            int i = 0;
+            while (i < hlit + hdist) {
+                int sym = clh.decode(br);
+                if (sym < 0) return false;
+                if (sym < 16) {
+                    lengths[i++] = (uint8_t)sym;
+                } else {
+                    int rep, val = 0;
+                    if (sym == 16) {
+                        if (i == 0) return false;
+                        val = lengths[i - 1];
+                        rep = 3 + (int)br.bits(2);
+                    } else if (sym == 17) {
+                        rep = 3 + (int)br.bits(3);
+                    } else {
+                        rep = 11 + (int)br.bits(7);
+                    }
+                    if (i + rep > hlit + hdist) return false;
+                    while (rep--) lengths[i++] = (uint8_t)val;
+                }
+            }
+            lit.build(lengths, hlit);
+            dist.build(lengths + hlit, hdist);
+        } else {
+            return false;
+        }
+        for (;;) {
+            int sym = lit.decode(br);
+            if (sym < 0 || br.fail) return false;
+            if (sym < 256) {
+                out.push_back((uint8_t)sym);
+            } else if (sym == 256) {
+                break;
+            } else {
+                sym -= 257;
+                if (sym >= 29) return false;
+                int len = len_base[sym] + (int)br.bits(len_extra[sym]);
+                int ds = dist.decode(br);
+                if (ds < 0 || ds >= 30) return false;
+                size_t d = dist_base[ds] + br.bits(dist_extra[ds]);
+                if (br.fail || d > out.size()) return false;
+                size_t from = out.size() - d;
+                for (int k = 0; k < len; k++) out.push_back(out[from + (size_t)k]);
+            }
+        }
+    } while (!final_block);
+    return true;
+}
+
+uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int paeth(int a, int b, int c) {
+    int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    return pb <= pc ? b : c;
+}
+
+} // namespace
+
+extern "C" int pth_load_png(const char *path, int *width, int *height, uint8_t **rgba) {
+    std::vector<uint8_t> bytes;
+    if (!read_file(path, bytes)) return set_error("unable to read image %s", path);
+    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    if (bytes.size() < 33 || memcmp(bytes.data(), sig, 8) != 0) return set_error("%s: not a PNG file", path);
+    size_t p = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, color = 0, interlace = 0;
+    std::vector<uint8_t> idat, palette, trns;
+    while (p + 12 <= bytes.size()) {
+        uint32_t len = be32(&bytes[p]);
+        const uint8_t *type = &bytes[p + 4];
+        const uint8_t *body = &bytes[p + 8];
+        if (p + 12 + (size_t)len > bytes.size()) return set_error("%s: truncated PNG chunk", path);
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(body);
+            h = be32(body + 4);
+            depth = body[8];
+            color = body[9];
+            interlace = body[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            palette.assign(body, body + len);
+        } else if (!memcmp(type, "tRNS", 4)) {
+            trns.assign(body, body + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), body, body + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        p += 12 + (size_t)len;
+    }
+    if (!w || !h || depth != 8 || interlace) return set_error("%s: only 8-bit non-interlaced PNGs are decoded", path);
+    int channels = color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : color == 6 ? 4 : 0;
+    if (!channels) return set_error("%s: unknown PNG colour type %d", path, color);
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * ((size_t)w * (size_t)channels + 1));
+    if (!inflate_zlib(idat.data(), idat.size(), raw)) return set_error("%s: corrupt PNG data", path);
+    size_t stride = (size_t)w * (size_t)channels;
+    if (raw.size() < (size_t)h * (stride + 1)) return set_error("%s: short PNG data", path);
+    std::vector<uint8_t> img((size_t)h * stride);
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t *src = &raw[(size_t)y * (stride + 1)];
+        uint8_t filter = src[0];
+        src++;
+        uint8_t *dst = &img[(size_t)y * stride];
+        const uint8_t *up = y ? dst - stride : nullptr;
+        for (size_t x = 0; x < stride; x++) {
+            int a = x >= (size_t)channels ? dst[x - (size_t)channels] : 0;
+            int b = up ? up[x] : 0;
+            int c = (up && x >= (size_t)channels) ? up[x - (size_t)channels] : 0;
+            int v = src[x];
+            switch (filter) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) >> 1; break;
+            case 4: v += paeth(a, b, c); break;
+            default: return set_error("%s: bad PNG filter", path);
+            }
+            dst[x] = (uint8_t)v;
+        }
+    }
+    uint8_t *out = (uint8_t *)malloc((size_t)w * (size_t)h * 4);
+    if (!out) return set_error("out of memory");
+    for (size_t i = 0; i < (size_t)w * (size_t)h; i++) {
+        const uint8_t *s = &img[i * (size_t)channels];
+        uint8_t *d = out + 4 * i;
+        switch (color) {
+        case 0: d[0] = d[1] = d[2] = s[0]; d[3] = 255; break;
+        case 2: d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 255; break;
+        case 3: {
+            size_t k = s[0];
+            d[0] = k * 3 + 2 < palette.size() ? palette[k * 3] : 0;
+            d[1] = k * 3 + 2 < palette.size() ? palette[k * 3 + 1] : 0;
+            d[2] = k * 3 + 2 < palette.size() ? palette[k * 3 + 2] : 0;
+            d[3] = k < trns.size() ? trns[k] : 255;
+            break;
+        }
+        case 4: d[0] = d[1] = d[2] = s[0]; d[3] = s[1]; break;
+        default: d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; break;
+        }
+    }
+    *width = (int)w;
+    *height = (int)h;
+    *rgba = out;
+    return 0;
+}
+
+// ---- tonemap (src/image.cu:11-99) ---------------------------------------------------
+
+namespace {
+
+inline float luminance(pt_vec3 v) { return dot(v, v3(0.2126f, 0.7152f, 0.0722f)); }
+
+inline uint8_t to_byte(float c) {
+    if (c != c) return 0; // NaN from a pure-black pixel (0/0): x86 yields 0 in the reference
+    if (c < 0.0) c = 0.0f;
+    if (c >= 1.0) c = 1.0f;
+    return (uint8_t)(255 * c);
+}
+
+inline float srgb_gamma(float c) {
+    if (c <= 0.0031308) return (float)(12.92 * c);
+    return (float)(1.055 * powf(c, (float)(1 / 2.4)) - 0.055);
+}
+
+} // namespace
+
+extern "C" int pth_tonemap_rgb8(const float *linear_rgb, int width, int height, uint8_t *rgb8) {
+    const pt_vec3 *px = (const pt_vec3 *)linear_rgb;
+    float white = luminance(v3(1, 1, 1));
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            pt_vec3 c = px[(size_t)y * (size_t)width + (size_t)x];
+            if (!std::isfinite(c.x) || !std::isfinite(c.y) || !std::isfinite(c.z)) {
+                set_error("pixel (%f, %f, %f) is not finite at (%d,%d)", c.x, c.y, c.z, x, y);
+                return 1;
+            }
+            white = fmaxf(white, luminance(c));
+        }
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            pt_vec3 c = px[(size_t)y * (size_t)width + (size_t)x];
+            // reinhard_extended_luminance + change_luminance
+            float l_old = luminance(c);
+            float numerator = l_old * (1.0f + (l_old / (white * white)));
+            float l_new = numerator / (1.0f + l_old);
+            c = scale(c, l_new / l_old);
+            size_t i = (size_t)(height - 1 - y) * (size_t)width + (size_t)x;
+            rgb8[3 * i + 0] = to_byte(srgb_gamma(c.x));
+            rgb8[3 * i + 1] = to_byte(srgb_gamma(c.y));
+            rgb8[3 * i + 2] = to_byte(srgb_gamma(c.z));
+        }
+    return 0;
+}
+
+// ---- PNG encode ------------------------------------------------------------------------
+
+namespace {
+
+uint32_t crc_table[256];
+bool crc_ready = false;
+uint32_t crc32_update(uint32_t crc, const uint8_t *data, size_t n) {
+    if (!crc_ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[i] = c;
+        }
+        crc_ready = true;
+    }
+    for (size_t i = 0; i < n; i++) crc = crc_table[(crc ^ data[i]) & 0xFF] ^ (crc >> 8);
+    return crc;
+}
+
+void put_be32(std::vector<uint8_t> &v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24));
+    v.push_back((uint8_t)(x >> 16));
+    v.push_back((uint8_t)(x >> 8));
+    v.push_back((uint8_t)x);
+}
+
+void put_chunk(std::vector<uint8_t> &file, const char *type, const std::vector<uint8_t> &body) {
+    put_be32(file, (uint32_t)body.size());
+    size_t at = file.size();
+    file.insert(file.end(), type, type + 4);
+    file.insert(file.end(), body.begin(), body.end());
+    uint32_t crc = crc32_update(0xFFFFFFFFu, &file[at], file.size() - at) ^ 0xFFFFFFFFu;
+    put_be32(file, crc);
+}
+
+} // namespace
+
+extern "C" int pth_write_png_rgb8(const uint8_t *rgb8, int width, int height, const char *filename) {
+    if (width <= 0 || height <= 0) return set_error("pth_write_png_rgb8: empty image");
+    size_t stride = (size_t)width * 3;
+    std::vector<uint8_t> raw;
+    raw.reserve(((size_t)height) * (stride + 1));
+    for (int y = 0; y < height; y++) {
+        raw.push_back(0); // filter: none
+        raw.insert(raw.end(), rgb8 + (size_t)y * stride, rgb8 + (size_t)(y + 1) * stride);
+    }
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78);
+    z.push_back(0x01);
+    size_t pos = 0;
+    uint32_t a = 1, b = 0;
+    while (pos < raw.size()) {
+        size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF));
+        z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF));
+        z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+        for (size_t i = 0; i < n; i++) {
+            a += raw[pos + i];
+            if (a >= 65521) a -= 65521;
+            b += a;
+            if (b >= 65521) b -= 65521;
+        }
+        pos += n;
+    }
+    put_be32(z, (b << 16) | a);
+
+    std::vector<uint8_t> file = {137, 80, 78, 71, 13, 10, 26, 10};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)width);
+    put_be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8);
+    ihdr.push_back(2);
+    ihdr.push_back(0);
+    ihdr.push_back(0);
+    ihdr.push_back(0);
+    put_chunk(file, "IHDR", ihdr);
+    put_chunk(file, "IDAT", z);
+    put_chunk(file, "IEND", {});
+    FILE *f = fopen(filename, "wb");
+    if (!f) return set_error("unable to open %s for writing", filename);
+    size_t wrote = fwrite(file.data(), 1, file.size(), f);
+    fclose(f);
+    return wrote == file.size() ? 0 : set_error("short write to %s", filename);
+}
+
+extern "C" int pth_write_image(const float *linear_rgb, int width, int height, const char *filename) {
+    const char *dot = strrchr(filename, '.');
+    if (!dot || strcmp(dot + 1, "png") != 0) return set_error("Unsupported output image type: %s", dot ? dot + 1 : "");
+    std::vector<uint8_t> buf((size_t)width * (size_t)height * 3);
+    if (pth_tonemap_rgb8(linear_rgb, width, height, buf.data())) return 1;
+    return pth_write_png_rgb8(buf.data(), width, height, filename);
+}

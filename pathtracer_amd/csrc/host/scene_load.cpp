@@ -1,0 +1,631 @@
+// scene_load.cpp — glTF 2.0 -> scene arrays.
+//
+// Restates Scene::read_gltf and its helpers (reference src/scene.cu:24-626,
+// 839-972). The reference leans on tinygltf; this reader parses the JSON itself
+// (mini_json.h) and keeps tinygltf's defaults where the reference relies on
+// them (metallic = roughness = 1, alphaCutoff 0.5, baseColorFactor 1,1,1,1,
+// alphaMode OPAQUE, sampler wrap REPEAT, texture indices -1).
+//
+// What decides the kernel's input and is therefore kept exact:
+//   * node transform = parent * (T * (R * (S * I))), float maths   scene.cu:34-108
+//   * camera from M*(0,0,0), M*(0,0,-1), M*(0,1,0) - position      scene.cu:110-132
+//   * lights: position M*(0,0,0), direction normalize(L*(0,0,-1))  scene.cu:134-173
+//   * materials: emissive = strength * factor, strength default 0  scene.cu:193-255
+//   * positions by M with a divide by w, normals/tangents by the
+//     linear part (not inverse-transpose) then normalised          scene.cu:527-556
+//   * vertex and face order = traversal order                      scene.cu:607-626
+//   * missing tangents -> pth_calculate_tangents                   scene.cu:595-600
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_internal.h"
+#include "hostmath.h"
+#include "mini_json.h"
+#include "pthost.h"
+
+void pth_scene::refresh_desc() {
+    desc.vertices = vertices.data();
+    desc.vertex_count = (uint32_t)vertices.size();
+    desc.faces = faces.data();
+    desc.face_count = (uint32_t)faces.size();
+    desc.lights = lights.data();
+    desc.light_count = (uint32_t)lights.size();
+    desc.materials = materials.data();
+    desc.material_count = (uint32_t)materials.size();
+    for (size_t i = 0; i < textures.size(); i++) textures[i].pixels = texel_storage[i].data();
+    desc.textures = textures.data();
+    desc.texture_count = (uint32_t)textures.size();
+}
+
+namespace pth {
+
+namespace {
+
+struct LoadError {
+    std::string msg;
+};
+
+[[noreturn]] void fail(const std::string &m) { throw LoadError{m}; }
+
+struct Document {
+    JsonValue root;
+    std::vector<std::vector<uint8_t>> buffers;
+    std::string dir;
+};
+
+std::string parent_dir(const std::string &path) {
+    size_t slash = path.find_last_of('/');
+    return slash == std::string::npos ? std::string(".") : path.substr(0, slash);
+}
+
+std::string extension_of(const std::string &path) {
+    size_t dot = path.find_last_of('.');
+    size_t slash = path.find_last_of('/');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return "";
+    return path.substr(dot + 1);
+}
+
+std::vector<uint8_t> base64_decode(const std::string &s, size_t from) {
+    static int8_t table[256];
+    static bool init = false;
+    if (!init) {
+        memset(table, -1, sizeof(table));
+        const char *abc = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+        for (int i = 0; i < 64; i++) table[(uint8_t)abc[i]] = (int8_t)i;
+        init = true;
+    }
+    std::vector<uint8_t> out;
+    uint32_t acc = 0;
+    int bits = 0;
+    for (size_t i = from; i < s.size(); i++) {
+        int8_t v = table[(uint8_t)s[i]];
+        if (v < 0) continue;
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            out.push_back((uint8_t)(acc >> bits));
+        }
+    }
+    return out;
+}
+
+M4 node_transform(const JsonValue &node) {
+    const JsonValue &mat = node.at("matrix");
+    if (mat.is_array() && mat.size() == 16) {
+        // column-major in the file (scene.cu:35-60)
+        M4 r;
+        for (int c = 0; c < 4; c++)
+            for (int row = 0; row < 4; row++) r.m[row][c] = (float)mat[(size_t)(c * 4 + row)].num;
+        return r;
+    }
+    M4 forward = M4::identity();
+    const JsonValue &s = node.at("scale");
+    if (s.is_array() && s.size() >= 3) {
+        M4 m = M4::identity();
+        m.m[0][0] = (float)s[0].num;
+        m.m[1][1] = (float)s[1].num;
+        m.m[2][2] = (float)s[2].num;
+        forward = mul(m, forward);
+    }
+    const JsonValue &q = node.at("rotation");
+    if (q.is_array() && q.size() >= 4) {
+        float qi = (float)q[0].num, qj = (float)q[1].num, qk = (float)q[2].num, qr = (float)q[3].num;
+        float k = 1; // quaternion assumed normalised (scene.cu:80)
+        M4 m = M4::identity();
+        m.m[0][0] = 1 - 2 * k * (qj * qj + qk * qk);
+        m.m[0][1] = 2 * k * (qi * qj - qk * qr);
+        m.m[0][2] = 2 * k * (qi * qk + qj * qr);
+        m.m[1][0] = 2 * k * (qi * qj + qk * qr);
+        m.m[1][1] = 1 - 2 * k * (qi * qi + qk * qk);
+        m.m[1][2] = 2 * k * (qj * qk - qi * qr);
+        m.m[2][0] = 2 * k * (qi * qk - qj * qr);
+        m.m[2][1] = 2 * k * (qj * qk + qi * qr);
+        m.m[2][2] = 1 - 2 * k * (qi * qi + qj * qj);
+        forward = mul(m, forward);
+    }
+    const JsonValue &t = node.at("translation");
+    if (t.is_array() && t.size() >= 3) {
+        M4 m = M4::identity();
+        m.m[0][3] = (float)t[0].num;
+        m.m[1][3] = (float)t[1].num;
+        m.m[2][3] = (float)t[2].num;
+        forward = mul(m, forward);
+    }
+    return forward;
+}
+
+int component_size(int component_type) {
+    switch (component_type) {
+    case 5120: case 5121: return 1;
+    case 5122: case 5123: return 2;
+    case 5125: case 5126: return 4;
+    default: return 0;
+    }
+}
+int type_arity(const std::string &type) {
+    if (type == "SCALAR") return 1;
+    if (type == "VEC2") return 2;
+    if (type == "VEC3") return 3;
+    if (type == "VEC4") return 4;
+    if (type == "MAT2") return 4;
+    if (type == "MAT3") return 9;
+    if (type == "MAT4") return 16;
+    return 0;
+}
+
+struct AccessorView {
+    const uint8_t *base;
+    size_t count;
+    size_t stride;
+    int component_type;
+    size_t available; // bytes from base to the end of the buffer
+};
+
+AccessorView open_accessor(const Document &doc, int index) {
+    const JsonValue &accs = doc.root.at("accessors");
+    if (index < 0 || (size_t)index >= accs.size()) fail("accessor index out of range");
+    const JsonValue &acc = accs[(size_t)index];
+    if (acc.has("sparse")) fail("sparse accessors are not supported"); // scene.cu:286
+    int bv_index = acc.at("bufferView").int_or(-1);
+    const JsonValue &bvs = doc.root.at("bufferViews");
+    if (bv_index < 0 || (size_t)bv_index >= bvs.size()) fail("bufferView index out of range");
+    const JsonValue &bv = bvs[(size_t)bv_index];
+    int buf_index = bv.at("buffer").int_or(-1);
+    if (buf_index < 0 || (size_t)buf_index >= doc.buffers.size()) fail("buffer index out of range");
+    const std::vector<uint8_t> &buf = doc.buffers[(size_t)buf_index];
+
+    AccessorView v;
+    v.component_type = acc.at("componentType").int_or(0);
+    v.count = (size_t)acc.at("count").number_or(0);
+    int elem = component_size(v.component_type) * type_arity(acc.at("type").string_or(""));
+    if (elem == 0) fail("accessor has an unknown type");
+    size_t bv_stride = (size_t)bv.at("byteStride").number_or(0);
+    v.stride = bv_stride ? bv_stride : (size_t)elem; // Accessor::ByteStride
+    size_t offset = (size_t)acc.at("byteOffset").number_or(0) + (size_t)bv.at("byteOffset").number_or(0);
+    if (v.count && offset + v.stride * (v.count - 1) + (size_t)elem > buf.size()) fail("accessor runs past its buffer");
+    v.base = buf.data() + offset;
+    v.available = buf.size() - offset;
+    return v;
+}
+
+// scene.cu:257-319 — bytes are reinterpreted as float whatever componentType says.
+void read_float_accessor(const Document &doc, int index, int arity, std::vector<pt_vec4> &out) {
+    AccessorView v = open_accessor(doc, index);
+    out.reserve(v.count);
+    for (size_t i = 0; i < v.count; i++) {
+        float item[4] = {0, 0, 0, 0};
+        size_t want = sizeof(float) * (size_t)arity;
+        if (v.stride * i + want > v.available) fail("float accessor runs past its buffer");
+        memcpy(item, v.base + v.stride * i, want);
+        out.push_back(pt_vec4{item[0], item[1], item[2], item[3]});
+    }
+}
+
+// scene.cu:321-369
+void read_index_accessor(const Document &doc, int index, std::vector<uint32_t> &out) {
+    AccessorView v = open_accessor(doc, index);
+    out.reserve(v.count);
+    int lo = 2147483647, hi = -1;
+    for (size_t i = 0; i < v.count; i++) {
+        const uint8_t *p = v.base + v.stride * i;
+        int value;
+        switch (v.component_type) {
+        case 5123: { uint16_t t; memcpy(&t, p, 2); value = (int)t; break; }
+        case 5125: { uint32_t t; memcpy(&t, p, 4); value = (int)t; break; }
+        case 5121: value = (int)*p; break;
+        default: fail("Component type not implemented: " + std::to_string(v.component_type));
+        }
+        lo = std::min(lo, value);
+        hi = std::max(hi, value);
+        out.push_back((uint32_t)value);
+    }
+    pth_log(4, "Indices scanned in range [%d, %d]\n", lo, hi);
+}
+
+struct Builder {
+    const Document &doc;
+    pth_scene &scene;
+    std::vector<pt_camera> cameras;
+
+    void camera(const JsonValue &node, const M4 &M) {
+        const JsonValue &cams = doc.root.at("cameras");
+        int idx = node.at("camera").int_or(-1);
+        if (idx < 0 || (size_t)idx >= cams.size()) fail("camera index out of range");
+        const JsonValue &cam = cams[(size_t)idx];
+        std::string type = cam.at("type").string_or("");
+        if (type != "perspective") fail("unsupported camera type: " + type);
+        pt_camera c;
+        c.yfov = (float)cam.at("perspective").at("yfov").number_or(0);
+        c.position = dehomogenise(mul(M, pt_vec4{0, 0, 0, 1}));
+        c.target = dehomogenise(mul(M, pt_vec4{0, 0, -1, 1}));
+        c.updir = sub(dehomogenise(mul(M, pt_vec4{0, 1, 0, 1})), c.position);
+        cameras.push_back(c);
+    }
+
+    void light(int idx, const M4 &M) {
+        const JsonValue &lights = doc.root.at("extensions").at("KHR_lights_punctual").at("lights");
+        if (idx < 0 || (size_t)idx >= lights.size()) fail("light index out of range");
+        const JsonValue &src = lights[(size_t)idx];
+        pt_light l;
+        l.color = v3(1, 1, 1);
+        const JsonValue &col = src.at("color");
+        if (col.is_array() && col.size() >= 3) l.color = v3((float)col[0].num, (float)col[1].num, (float)col[2].num);
+        l.intensity = (float)src.at("intensity").number_or(1.0);
+        l.position = dehomogenise(mul(M, pt_vec4{0, 0, 0, 1}));
+        l.direction = normalized(mul_linear(M, v3(0, 0, -1)));
+        std::string type = src.at("type").string_or("");
+        if (type == "directional") {
+            l.type = PT_LIGHT_DIRECTIONAL;
+            pth_log(4, "parsing directional light: \n");
+        } else if (type == "point") {
+            l.type = PT_LIGHT_POINT;
+            pth_log(4, "parsing point light: \n");
+        } else {
+            fail("Unsupported light '" + type + "'");
+        }
+        scene.lights.push_back(l);
+    }
+
+    void mesh(const JsonValue &node, const M4 &M) {
+        pth_log(4, "Parsing mesh of node: %s\n", node.at("name").string_or("").c_str());
+        const JsonValue &meshes = doc.root.at("meshes");
+        int idx = node.at("mesh").int_or(-1);
+        if (idx < 0 || (size_t)idx >= meshes.size()) fail("mesh index out of range");
+        const JsonValue &prims = meshes[(size_t)idx].at("primitives");
+        for (size_t p = 0; p < prims.size(); p++) primitive(prims[p], M);
+        pth_log(4, "Done with mesh\n");
+    }
+
+    void primitive(const JsonValue &prim, const M4 &M) {
+        pth_log(4, "Parsing primitive\n");
+        int mode = prim.at("mode").int_or(4);
+        if (mode != 4) fail("only triangle primitives are supported");
+        int material = prim.at("material").int_or(-1);
+        if (material < 0 || (size_t)material >= scene.materials.size())
+            fail("primitive without a valid material (" + std::to_string(material) + ")");
+
+        std::vector<pt_vec4> positions, normals, tangents, uvs;
+        std::vector<uint32_t> indices;
+        const JsonValue &attrs = prim.at("attributes");
+        for (const auto &kv : attrs.obj) {
+            int acc = kv.second.int_or(-1);
+            if (kv.first == "POSITION") {
+                pth_log(4, "Scanning POSITION\n");
+                read_float_accessor(doc, acc, 3, positions);
+            } else if (kv.first == "NORMAL") {
+                pth_log(4, "Scanning NORMAL\n");
+                read_float_accessor(doc, acc, 3, normals);
+            } else if (kv.first == "TANGENT") {
+                pth_log(4, "Scanning TANGENT\n");
+                read_float_accessor(doc, acc, 4, tangents);
+            } else if (kv.first == "TEXCOORD_0") {
+                pth_log(4, "Scanning TEXCOORD_0\n");
+                read_float_accessor(doc, acc, 2, uvs);
+            } else {
+                pth_log(2, "skipped unsupported attribute '%s'\n", kv.first.c_str());
+            }
+        }
+        pth_log(4, "Scanning INDICES\n");
+        if (!prim.has("indices")) fail("non-indexed primitives are not supported");
+        read_index_accessor(doc, prim.at("indices").int_or(-1), indices);
+
+        size_t vert_count = positions.size();
+        if (!vert_count) fail("primitive without POSITION data");
+        bool has_normals = !normals.empty();
+        bool has_tangents = !tangents.empty();
+        bool has_uvs = !uvs.empty();
+        if (has_normals && normals.size() != vert_count) fail("NORMAL count differs from POSITION count");
+        if (has_tangents && tangents.size() != vert_count) fail("TANGENT count differs from POSITION count");
+        if (has_uvs && uvs.size() != vert_count) fail("TEXCOORD_0 count differs from POSITION count");
+        if (indices.empty() || indices.size() % 3) fail("index count is not a positive multiple of 3");
+        // The reference asserts here (scene.cu:586): flat shading needs a face
+        // tangent it never computes.
+        if (!has_normals) fail("primitive without NORMAL: flat shading is not supported by the reference either");
+
+        pth_log(4, "Adding faces\n");
+        uint32_t first_vertex = (uint32_t)scene.vertices.size();
+        for (size_t i = 0; i < vert_count; i++) {
+            pt_vertex v;
+            pt_vec4 p = positions[i];
+            v.position = dehomogenise(mul(M, pt_vec4{p.x, p.y, p.z, 1.0f}));
+            v.normal = normalized(mul_linear(M, v3(normals[i].x, normals[i].y, normals[i].z)));
+            if (has_tangents) {
+                pt_vec3 tw = normalized(mul_linear(M, v3(tangents[i].x, tangents[i].y, tangents[i].z)));
+                v.tangent = pt_vec4{tw.x, tw.y, tw.z, tangents[i].w};
+            } else {
+                v.tangent = pt_vec4{0, 0, 0, 0};
+            }
+            v.texcoord0 = has_uvs ? v3(uvs[i].x, uvs[i].y, 0) : v3(0, 0, 0);
+            scene.vertices.push_back(v);
+        }
+
+        uint32_t first_face = (uint32_t)scene.faces.size();
+        for (size_t i = 0; i < indices.size(); i += 3) {
+            pt_face f;
+            memset(&f, 0, sizeof(f));
+            f.material = (uint32_t)material;
+            f.vertexCount = 3;
+            for (int k = 0; k < 3; k++) {
+                if (indices[i + k] >= vert_count) fail("index past the primitive's vertex count");
+                f.vertices[k] = first_vertex + indices[i + k];
+            }
+            f.shading = PT_BARY_SHADING;
+            scene.faces.push_back(f);
+        }
+
+        if (!has_tangents) {
+            uint32_t num_faces = (uint32_t)scene.faces.size() - first_face;
+            if (pth_calculate_tangents(scene.vertices.data(), (uint32_t)scene.vertices.size(), scene.faces.data(),
+                                       first_face, num_faces))
+                fail(std::string("tangent calculation failed: ") + pth_last_error());
+        }
+        pth_log(4, "Done with primitive\n");
+    }
+
+    void node(int node_index, const M4 &parent) {
+        const JsonValue &nodes = doc.root.at("nodes");
+        if (node_index < 0 || (size_t)node_index >= nodes.size()) fail("node index out of range");
+        const JsonValue &n = nodes[(size_t)node_index];
+        M4 M = mul(parent, node_transform(n));
+        if (n.has("camera")) camera(n, M);
+        const JsonValue &lext = n.at("extensions").at("KHR_lights_punctual").at("light");
+        if (lext.is_number()) light((int)lext.num, M);
+        if (n.has("mesh")) mesh(n, M);
+        const JsonValue &children = n.at("children");
+        for (size_t i = 0; i < children.size(); i++) node(children[i].int_or(-1), M);
+    }
+};
+
+void parse_material(pth_scene &scene, const JsonValue &m) {
+    pt_material mat;
+    memset(&mat, 0, sizeof(mat));
+    std::string name = m.at("name").string_or("");
+    strncpy(mat.name, name.c_str(), PT_MATERIAL_NAME_SIZE - 1);
+
+    float emissive_strength = 0, transmission = 0, ior = 1.3f, specular = 0; // scene.cu:201-204
+    const JsonValue &ext = m.at("extensions");
+    for (const auto &kv : ext.obj) {
+        if (kv.first == "KHR_materials_emissive_strength") {
+            emissive_strength = (float)kv.second.at("emissiveStrength").number_or(0);
+        } else if (kv.first == "KHR_materials_transmission") {
+            transmission = (float)kv.second.at("transmissionFactor").number_or(0);
+        } else if (kv.first == "KHR_materials_ior") {
+            ior = (float)kv.second.at("ior").number_or(0);
+        } else if (kv.first == "KHR_materials_specular") {
+            specular = (float)kv.second.at("specularFactor").number_or(0);
+        } else {
+            pth_log(2, "Unknown extension: %s\n", kv.first.c_str());
+        }
+    }
+
+    const JsonValue &pbr = m.at("pbrMetallicRoughness");
+    mat.alphaCutoff = (float)m.at("alphaCutoff").number_or(0.5);
+    mat.baseColorFactor = pt_vec4{1, 1, 1, 1};
+    const JsonValue &bc = pbr.at("baseColorFactor");
+    if (bc.is_array() && bc.size() >= 4)
+        mat.baseColorFactor = pt_vec4{(float)bc[0].num, (float)bc[1].num, (float)bc[2].num, (float)bc[3].num};
+    pt_vec3 ef = v3(0, 0, 0);
+    const JsonValue &e = m.at("emissiveFactor");
+    if (e.is_array() && e.size() >= 3) ef = v3((float)e[0].num, (float)e[1].num, (float)e[2].num);
+    mat.emissive = scale(ef, emissive_strength);
+    mat.metallicFactor = (float)pbr.at("metallicFactor").number_or(1.0);
+    mat.roughnessFactor = (float)pbr.at("roughnessFactor").number_or(1.0);
+    mat.transmission = transmission;
+    mat.specular = specular;
+    mat.ior = ior;
+    mat.baseColorTexture = pbr.at("baseColorTexture").at("index").int_or(-1);
+    mat.normalTexture = m.at("normalTexture").at("index").int_or(-1);
+    mat.metallicRoughnessTexture = pbr.at("metallicRoughnessTexture").at("index").int_or(-1);
+    std::string mode = m.at("alphaMode").string_or("OPAQUE");
+    mat.alphaMode = mode == "MASK" ? PT_ALPHA_MASK : (mode == "BLEND" ? PT_ALPHA_BLEND : PT_ALPHA_OPAQUE);
+    if (pbr.at("baseColorTexture").at("texCoord").int_or(0) != 0) pth_log(2, "TODO implement other texCoords");
+
+    pth_log(4, "Material:\n");
+    pth_log(4, "  Name: %s\n", mat.name);
+    pth_log(4, "  BaseColorFactor: (%.2f, %.2f, %.2f; %.2f)\n", mat.baseColorFactor.x, mat.baseColorFactor.y,
+            mat.baseColorFactor.z, mat.baseColorFactor.w);
+    pth_log(4, "  Color texture: (%d)\n", mat.baseColorTexture);
+    pth_log(4, "  Normal texture: (%d)\n", mat.normalTexture);
+    pth_log(4, "  Transmission: %.2f\n", mat.transmission);
+    pth_log(4, "  Emissive: (%.2f, %.2f, %.2f)\n", mat.emissive.x, mat.emissive.y, mat.emissive.z);
+    pth_log(4, "  Metallic: %.2f\n", mat.metallicFactor);
+    pth_log(4, "  Roughness: %.2f\n", mat.roughnessFactor);
+    pth_log(4, "  Metallic roughness texture: (%d)\n", mat.metallicRoughnessTexture);
+    pth_log(4, "  Specular: %.2f\n", mat.specular);
+    pth_log(4, "  IoR: %.2f\n", mat.ior);
+    scene.materials.push_back(mat);
+}
+
+int wrap_mode(int gltf_wrap) { // scene.cu:632-643
+    switch (gltf_wrap) {
+    case 33071: return PT_WRAP_CLAMP;
+    case 33648: return PT_WRAP_MIRROR;
+    default: return PT_WRAP_REPEAT;
+    }
+}
+int filter_mode(int gltf_filter) { // scene.cu:649-662
+    switch (gltf_filter) {
+    case 9728: case 9984: case 9986: return PT_FILTER_POINT;
+    default: return PT_FILTER_LINEAR;
+    }
+}
+
+// load_image + load_texture, scene.cu:713-837
+void add_texture(pth_scene &scene, const std::string &path, int mag_filter, int wrap_s, int wrap_t) {
+    pth_log(4, "Loading image: %s\n", path.c_str());
+    std::string ext = extension_of(path);
+    pt_texture t;
+    memset(&t, 0, sizeof(t));
+    t.channels = 4;
+    t.wrapS = wrap_mode(wrap_s);
+    t.wrapT = wrap_mode(wrap_t);
+    t.filter = filter_mode(mag_filter); // magFilter wins (scene.cu:664)
+    std::vector<uint8_t> blob;
+    if (ext == "hdr") {
+        float *px = nullptr;
+        if (pth_load_hdr(path.c_str(), &t.width, &t.height, &px)) fail(pth_last_error());
+        t.isFloat = 1;
+        blob.assign((uint8_t *)px, (uint8_t *)px + sizeof(float) * 4 * (size_t)t.width * (size_t)t.height);
+        pth_free(px);
+    } else if (ext == "png") {
+        uint8_t *px = nullptr;
+        if (pth_load_png(path.c_str(), &t.width, &t.height, &px)) fail(pth_last_error());
+        t.isFloat = 0;
+        blob.assign(px, px + 4 * (size_t)t.width * (size_t)t.height);
+        pth_free(px);
+    } else {
+        fail("Unknown image extension: ." + ext + " (this build decodes .hdr and .png)");
+    }
+    pth_log(4, "Loaded image (w=%d, h=%d)\n", t.width, t.height);
+    scene.textures.push_back(t);
+    scene.texel_storage.push_back(std::move(blob));
+}
+
+void load_document(const std::string &path, Document &doc) {
+    std::vector<uint8_t> bytes;
+    if (!read_file(path, bytes)) fail("Failed to load glTF: " + path);
+    doc.dir = parent_dir(path);
+    std::vector<uint8_t> glb_bin;
+    std::string json_text;
+    if (extension_of(path) == "glb") {
+        if (bytes.size() < 20 || memcmp(bytes.data(), "glTF", 4) != 0) fail("not a GLB container");
+        size_t p = 12;
+        while (p + 8 <= bytes.size()) {
+            uint32_t len, type;
+            memcpy(&len, &bytes[p], 4);
+            memcpy(&type, &bytes[p + 4], 4);
+            p += 8;
+            if (p + len > bytes.size()) fail("GLB chunk runs past the file");
+            if (type == 0x4E4F534Au) json_text.assign((const char *)&bytes[p], len);
+            else if (type == 0x004E4942u) glb_bin.assign(bytes.begin() + (long)p, bytes.begin() + (long)(p + len));
+            p += len;
+        }
+    } else {
+        json_text.assign((const char *)bytes.data(), bytes.size());
+    }
+    try {
+        doc.root = JsonParser(json_text).parse();
+    } catch (const std::exception &e) {
+        fail(std::string("glTF parse error: ") + e.what());
+    }
+    const JsonValue &buffers = doc.root.at("buffers");
+    for (size_t i = 0; i < buffers.size(); i++) {
+        std::vector<uint8_t> data;
+        std::string uri = buffers[i].at("uri").string_or("");
+        if (uri.empty()) {
+            data = glb_bin;
+        } else if (uri.compare(0, 5, "data:") == 0) {
+            size_t comma = uri.find(',');
+            if (comma == std::string::npos) fail("malformed data URI");
+            data = base64_decode(uri, comma + 1);
+        } else {
+            if (!read_file(doc.dir + "/" + uri, data)) fail("unable to read buffer " + doc.dir + "/" + uri);
+        }
+        doc.buffers.push_back(std::move(data));
+    }
+}
+
+} // namespace
+
+} // namespace pth
+
+using namespace pth;
+
+extern "C" int pth_scene_load_gltf(const char *path, const pth_config *cfg, pth_scene **out) {
+    if (!path || !out) return set_error("pth_scene_load_gltf: null argument");
+    *out = nullptr;
+    pth_log(3, "Parsing .gltf... \n");
+    pth_scene *scene = new pth_scene();
+    try {
+        Document doc;
+        load_document(path, doc);
+
+        // IMAGES + TEXTURES (scene.cu:889-909): one texture per glTF texture
+        const JsonValue &images = doc.root.at("images");
+        const JsonValue &samplers = doc.root.at("samplers");
+        const JsonValue &textures = doc.root.at("textures");
+        for (size_t i = 0; i < textures.size(); i++) {
+            int source = textures[i].at("source").int_or(-1);
+            int sampler = textures[i].at("sampler").int_or(-1);
+            pth_log(4, "Creating texture: source=%d, sampler=%d\n", source, sampler);
+            if (source < 0 || (size_t)source >= images.size()) fail("texture source out of range");
+            std::string uri = images[(size_t)source].at("uri").string_or("");
+            if (uri.empty()) fail("images without a uri are not supported");
+            int mag = -1, ws = 10497, wt = 10497;
+            if (sampler >= 0 && (size_t)sampler < samplers.size()) {
+                mag = samplers[(size_t)sampler].at("magFilter").int_or(-1);
+                ws = samplers[(size_t)sampler].at("wrapS").int_or(10497);
+                wt = samplers[(size_t)sampler].at("wrapT").int_or(10497);
+            }
+            add_texture(*scene, doc.dir + "/" + uri, mag, ws, wt);
+        }
+
+        const JsonValue &materials = doc.root.at("materials");
+        for (size_t i = 0; i < materials.size(); i++) parse_material(*scene, materials[i]);
+
+        Builder b{doc, *scene, {}};
+        int default_scene = doc.root.at("scene").int_or(0);
+        const JsonValue &scenes = doc.root.at("scenes");
+        if (default_scene < 0 || (size_t)default_scene >= scenes.size()) fail("default scene out of range");
+        const JsonValue &roots = scenes[(size_t)default_scene].at("nodes");
+        for (size_t i = 0; i < roots.size(); i++) b.node(roots[i].int_or(-1), M4::identity());
+
+        // clear texture (scene.cu:925-936): linear filter, mirrored repeat
+        scene->desc.clearTexture = -1;
+        if (cfg && cfg->world_clear_color_texture[0]) {
+            add_texture(*scene, cfg->world_clear_color_texture, 9729, 33648, 33648);
+            scene->desc.clearTexture = (int32_t)scene->textures.size() - 1;
+        }
+
+        if (b.cameras.empty()) {
+            pth_log(2, "No camera found in scene! Placing default camera.\n");
+            if (!cfg) fail("scene has no camera and no default camera was given");
+            pt_camera c;
+            c.position = cfg->default_camera_position;
+            c.target = cfg->default_camera_target;
+            c.updir = cfg->default_camera_updir;
+            c.yfov = cfg->default_camera_yfov;
+            b.cameras.push_back(c);
+        } else if (b.cameras.size() > 1) {
+            pth_log(2, "Multiple cameras found in scene, choosing camera 0.\n");
+        }
+        scene->desc.camera = b.cameras[0];
+    } catch (const LoadError &e) {
+        delete scene;
+        pth_log(1, "%s\n", e.msg.c_str());
+        return set_error("%s", e.msg.c_str());
+    }
+    scene->refresh_desc();
+    pth_log(3, "Done parsing .gltf\n");
+    *out = scene;
+    return 0;
+}
+
+extern "C" int pth_scene_from_desc(const pt_scene_desc *d, pth_scene **out) {
+    if (!d || !out) return set_error("pth_scene_from_desc: null argument");
+    pth_scene *s = new pth_scene();
+    s->vertices.assign(d->vertices, d->vertices + d->vertex_count);
+    s->faces.assign(d->faces, d->faces + d->face_count);
+    s->lights.assign(d->lights, d->lights + d->light_count);
+    s->materials.assign(d->materials, d->materials + d->material_count);
+    for (uint32_t i = 0; i < d->texture_count; i++) {
+        pt_texture t = d->textures[i];
+        size_t bytes = (size_t)t.width * (size_t)t.height * 4 * (t.isFloat ? sizeof(float) : 1);
+        const uint8_t *px = (const uint8_t *)t.pixels;
+        s->texel_storage.emplace_back(px, px + bytes);
+        s->textures.push_back(t);
+    }
+    s->desc.camera = d->camera;
+    s->desc.clearTexture = d->clearTexture;
+    s->refresh_desc();
+    *out = s;
+    return 0;
+}
+
+extern "C" const pt_scene_desc *pth_scene_get_desc(const pth_scene *scene) { return scene ? &scene->desc : nullptr; }
+
+extern "C" void pth_scene_free(pth_scene *scene) { delete scene; }

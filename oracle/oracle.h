@@ -1,0 +1,91 @@
+/* oracle.h — C ABI of the CPU oracle (liboracle.so).
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under pathtracer_amd/ may include, link or
+ * load this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg do, and there only as the checker / the timed CPU baseline.
+ *
+ * The oracle is a plain C++ restatement of the reference's render_kernel
+ * (/root/reference src/renderer.cu:361-405 and everything it calls), written to
+ * follow the reference's own structure: array-of-struct scene records, 40-byte
+ * BVH nodes walked with a 64-entry stack, the full hit record rebuilt at every
+ * closer hit, one closest-hit traversal per shadow ray and per light-pdf ray.
+ *
+ * PARITY UNPINNED for the first-party kernel logic: the reference ships no
+ * tests, golden vectors or fixtures for this path, and its
+ * sources cannot be built here (they need the CUDA runtime and cuRAND headers,
+ * which this image lacks; no stand-ins were written). What IS pinned:
+ *   - scene/BVH structure counts against the figures SURVEY.md §3.3 recorded
+ *     from the reference's builder (tests/test_host_pipeline.py);
+ *   - tangents against the vendored MikkTSpace C library built from its own
+ *     source into oracle/_ref (tests/test_tangents.py);
+ *   - the XORWOW step and 2^67 jump matrices against rocRAND's published tables
+ *     (tests/test_rng.py). cuRAND's seed-scramble constants are from the public
+ *     curand_kernel.h as recalled in SURVEY.md §8c — unverified here.
+ */
+#ifndef ORACLE_H_
+#define ORACLE_H_
+
+#include <stdint.h>
+
+#include "pt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    const pt_scene_desc *scene;
+    const pt_bvh_node *nodes;   uint32_t node_count;
+    const uint32_t *indices;    uint32_t index_count;
+    const pt_lst_node *lst;     uint32_t lst_count;
+    pt_render_config cfg;
+} orc_inputs;
+
+typedef struct {
+    uint64_t samples;        /* camera paths started */
+    uint64_t rays;           /* calls of the closest-hit routine (all kinds) */
+    uint64_t inner_visits;   /* inner nodes popped (two slab tests each) */
+    uint64_t tri_tests;      /* Moeller-Trumbore evaluations */
+    uint64_t hit_records;    /* full hit records written (every closer hit) */
+    uint64_t shaded_hits;    /* path vertices that reached shading */
+    uint64_t bounces;        /* BSDF samples taken */
+} orc_counters;
+
+/* One launch of render_kernel over the whole image (renderer.cu:361-405):
+ * img is W*H*3 floats, read and written (running mean with previous_samples).
+ * threads <= 0 picks hardware_concurrency. counters may be NULL. */
+int orc_render_batch(const orc_inputs *in, int seed, int previous_samples, int current_samples,
+                     float *img, int threads, orc_counters *counters);
+
+/* Same, restricted to rows [y0, y1) — the bounded CPU-baseline sample. */
+int orc_render_rows(const orc_inputs *in, int seed, int previous_samples, int current_samples,
+                    float *img, int y0, int y1, int threads, orc_counters *counters);
+
+/* First n outputs of curand(&state) after curand_init(seed, subsequence, 0). */
+void orc_rng_stream(uint64_t seed, uint64_t subsequence, uint32_t *out, int n);
+
+/* XORWOW state (v[0..4], d) right after curand_init(seed, subsequence, 0). */
+void orc_rng_state(uint64_t seed, uint64_t subsequence, uint32_t state[6]);
+
+/* The 160x160 GF(2) matrix A^(2^67 * 4^k) in rocRAND's table layout
+ * (800 words: row (i*32+j) holds the image of input bit j of word i). */
+void orc_rng_sequence_jump_matrix(int k, uint32_t out[800]);
+
+/* Face id of the first camera ray of every pixel (sample 0 of the batch seeded
+ * with `seed`), -1 on a miss. jitter=0 replaces the Box-Muller offsets by 0. */
+int orc_primary_hits(const orc_inputs *in, int seed, int jitter, int32_t *face_ids, float *distances);
+
+/* Software texture fetch, exposed for unit tests. */
+void orc_sample_texture(const pt_texture *tex, float u, float v, float rgba[4]);
+
+/* The deterministic math of pt_detmath.h, exposed for accuracy tests. */
+float orc_logf(float x);
+void orc_sincosf(float x, float *s, float *c);
+float orc_atan2f(float y, float x);
+float orc_acosf(float x);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ORACLE_H_ */

@@ -1,0 +1,117 @@
+/* ptcore.h — C ABI of the MI355X radiance kernel (libptcore.so).
+ *
+ * The reference has no plugin/FFI layer; the boundary of its hot path is the set
+ * of CUDA-runtime calls in src/main.cu around one kernel launch. Each entry
+ * point below replaces one of those interaction points. Plain
+ * pointers and sizes only; no torch, CUDA or HIP types in any signature.
+ *
+ * Errors: every call returns 0 on success, non-zero on failure with the text in
+ * pt_last_error() (the reference prints "CUDA error: %s" and exits,
+ * src/utils.cu:16-22; the CLI keeps that exit-on-error policy).
+ * Threading: one host thread per context; one launch in flight per context.
+ * Ownership: the library copies what it is handed; host arrays stay the
+ * caller's. Device copies are released by pt_destroy (the reference leaks
+ * them, src/main.cu:148-151).
+ */
+#ifndef PTCORE_H_
+#define PTCORE_H_
+
+#include <stdint.h>
+
+#include "pt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_context pt_context;
+
+/* Counters of the instrumented kernel variant (pt_count_batch). "rays" counts
+ * what the reference would have traced (one closest-hit walk per camera,
+ * bounce, shadow and light-pdf ray); "traversals" what this kernel walked. */
+typedef struct {
+    uint64_t samples;
+    uint64_t rays;
+    uint64_t inner_visits;
+    uint64_t tri_tests;
+    uint64_t traversals;
+    uint64_t shaded_hits;
+    uint64_t bounces;
+} pt_counters;
+
+const char *pt_last_error(void);
+
+/* Binds a context to HIP device `device` (replaces the implicit device 0 and
+ * default stream of src/main.cu). Builds the XORWOW 2^67 jump tables. */
+int pt_create(int device, pt_context **out);
+void pt_destroy(pt_context *ctx);
+
+/* d_scene.device_from_host(h_scene) — src/main.cu:74, src/scene.cu:974-990,
+ * src/scene.h:30-48. Copies the five arrays, camera and clear-texture index and
+ * re-lays them out for the kernel (per-face shading records, compact
+ * materials, texel arrays). */
+int pt_scene_upload(pt_context *ctx, const pt_scene_desc *scene);
+
+/* d_bvh.device_from_host(h_bvh) — src/main.cu:75, src/bvh.cu:347-359. Takes the
+ * reference-format node array (40 B nodes, only the first node_count are read)
+ * and face-index list; bakes 64 B two-child nodes and 48 B pre-gathered
+ * triangles. Call after pt_scene_upload. */
+int pt_bvh_upload(pt_context *ctx, const pt_bvh_node *nodes, uint32_t node_count,
+                  const uint32_t *indices, uint32_t index_count);
+
+/* d_lst.device_from_host(h_lst) — src/main.cu:76, src/lst.cu:36-46. */
+int pt_lst_upload(pt_context *ctx, const pt_lst_node *nodes, uint32_t count);
+
+/* The fields of config_t the kernel reads (resolution, exposure, clear colour;
+ * src/renderer.cu:298,366,383,393) and cudaMalloc(&d_img) — src/main.cu:78-83.
+ * (Re)allocates the library-owned accumulator, zero-filled (the reference
+ * leaves it uninitialised and relies on garbage * 0). */
+int pt_configure(pt_context *ctx, const pt_render_config *cfg);
+
+/* render_kernel<<<grid, block>>>(d_img, d_bvh, d_scene, d_lst, cfg, prev, cur)
+ * + cudaDeviceSynchronize — src/main.cu:104-106, src/renderer.cu:361-405.
+ * `seed` is cfg.seed of that launch (the host loop adds 1 per batch,
+ * src/main.cu:121). Blocking. Accumulates into the library-owned image. */
+int pt_render_batch(pt_context *ctx, int seed, int previous_samples, int current_samples);
+
+/* Same launch into a caller-owned DEVICE buffer of resolution_x*resolution_y*3
+ * floats, on a caller stream (hipStream_t passed as void*, NULL = the
+ * context's own stream), without synchronising. For callers that keep the
+ * accumulator in their own device memory (multi-GPU reduce, graphs). */
+int pt_render_batch_into(pt_context *ctx, float *device_img, void *stream, int seed,
+                         int previous_samples, int current_samples);
+
+/* cudaMemcpy(h_img, d_img, ..., DeviceToHost) — src/main.cu:111. Caller-owned
+ * host buffer of resolution_x*resolution_y*3 floats, row 0 = bottom row as in
+ * the reference (the flip happens at PNG write, src/image.cu:94). */
+int pt_read_image(pt_context *ctx, float *host_rgb);
+
+int pt_clear_image(pt_context *ctx);
+int pt_synchronize(pt_context *ctx);
+
+/* ---- verification / measurement hooks (no counterpart in the reference) ---- */
+
+/* First n outputs of the device XORWOW stream for (seed, subsequence, offset 0):
+ * what curand(&state) would return after curand_init (src/random.cu:3-5). */
+int pt_rng_stream(pt_context *ctx, uint64_t seed, uint64_t subsequence, uint32_t *host_out, int n);
+
+/* Face id hit by the first camera ray of every pixel (-1 = miss) and its
+ * distance; jitter = 0 zeroes the Box-Muller offsets. Host buffers of
+ * resolution_x*resolution_y entries; distances may be NULL. */
+int pt_primary_hits(pt_context *ctx, int seed, int jitter, int32_t *host_face_ids, float *host_distances);
+
+/* Runs the instrumented variant of one batch (does not touch the image). */
+int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt_counters *out);
+
+/* HIP-event duration (ms) of the most recent render launch of this context,
+ * measured on the stream it was launched on; waits for that launch. */
+float pt_last_kernel_ms(pt_context *ctx);
+
+/* Bytes of device memory held by the context (scene + BVH + LST + image). */
+uint64_t pt_device_footprint(pt_context *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PTCORE_H_ */

@@ -67,9 +67,17 @@ class HostBvh(C.Structure):  # pth_bvh
     ]
 
 
-class Counters(C.Structure):  # pt_counters / orc_counters (same seven fields)
+class Counters(C.Structure):  # orc_counters (oracle/oracle.h)
     _fields_ = [(n, C.c_uint64) for n in
                 ("samples", "rays", "inner_visits", "tri_tests", "hit_records", "shaded_hits", "bounces")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
+    _fields_ = [(n, C.c_uint64) for n in
+                ("samples", "rays", "inner_visits", "tri_tests", "traversals", "shaded_hits", "bounces")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -161,7 +169,7 @@ def core_lib():
     L.pt_synchronize.argtypes = [C.c_void_p]
     L.pt_rng_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
     L.pt_primary_hits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    L.pt_count_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Counters)]
+    L.pt_count_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CoreCounters)]
     L.pt_last_kernel_ms.argtypes = [C.c_void_p]
     L.pt_last_kernel_ms.restype = C.c_float
     L.pt_device_footprint.argtypes = [C.c_void_p]

@@ -1,0 +1,113 @@
+"""Device-side handle: a thin wrapper over the C ABI of include/ptcore.h.
+
+All compute happens in libptcore.so (hand-written HIP for gfx950). There is no CPU
+fallback: constructing a Renderer without the library or without a GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+class CoreError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc:
+        raise CoreError(_ffi.core_lib().pt_last_error().decode("utf-8", "replace"))
+
+
+class Renderer:
+    """One context = one GPU. Mirrors the device half of src/main.cu:74-111."""
+
+    def __init__(self, device=0):
+        self._lib = _ffi.core_lib()
+        self._ctx = C.c_void_p()
+        _check(self._lib.pt_create(int(device), C.byref(self._ctx)))
+        self.device = int(device)
+        self.width = self.height = 0
+        self._keep = []
+
+    # -- uploads -----------------------------------------------------------------------
+    def upload(self, scene, bvh, lst):
+        """d_scene / d_bvh / d_lst .device_from_host (src/main.cu:74-76)."""
+        _check(self._lib.pt_scene_upload(self._ctx, C.byref(scene.desc)))
+        nodes = np.ascontiguousarray(bvh.nodes)
+        indices = np.ascontiguousarray(bvh.indices)
+        _check(self._lib.pt_bvh_upload(self._ctx, nodes.ctypes.data, len(nodes), indices.ctypes.data, len(indices)))
+        ln = np.ascontiguousarray(lst.nodes)
+        _check(self._lib.pt_lst_upload(self._ctx, ln.ctypes.data if len(ln) else None, len(ln)))
+
+    def configure(self, width, height, exposure=0.0, clear_color=(0.0, 0.0, 0.0)):
+        cfg = _ffi.RenderConfig(int(width), int(height), float(exposure), _ffi.Vec3(*[float(c) for c in clear_color]))
+        _check(self._lib.pt_configure(self._ctx, C.byref(cfg)))
+        self.width, self.height = int(width), int(height)
+
+    # -- rendering ---------------------------------------------------------------------
+    def render_batch(self, seed, previous_samples, current_samples):
+        """One blocking launch into the library-owned accumulator (src/main.cu:104-106)."""
+        _check(self._lib.pt_render_batch(self._ctx, int(seed), int(previous_samples), int(current_samples)))
+
+    def render_batch_into(self, device_ptr, seed, previous_samples, current_samples, stream=None):
+        """Asynchronous launch into a caller-owned device buffer (data_ptr of a torch tensor)."""
+        _check(self._lib.pt_render_batch_into(self._ctx, C.c_void_p(int(device_ptr)),
+                                              C.c_void_p(int(stream)) if stream else None,
+                                              int(seed), int(previous_samples), int(current_samples)))
+
+    def render(self, seed, samples, samples_every_update):
+        """The batch loop of src/main.cu:101-133 without the per-batch PNG: seed+1 per batch."""
+        self.clear()
+        done = 0
+        while done < samples:
+            cur = min(samples_every_update, samples - done)
+            self.render_batch(seed, done, cur)
+            done += cur
+            seed += 1
+        return self.read_image()
+
+    def read_image(self):
+        img = np.empty((self.height, self.width, 3), np.float32)
+        _check(self._lib.pt_read_image(self._ctx, img.ctypes.data))
+        return img
+
+    def clear(self):
+        _check(self._lib.pt_clear_image(self._ctx))
+
+    def synchronize(self):
+        _check(self._lib.pt_synchronize(self._ctx))
+
+    # -- verification / measurement ------------------------------------------------------
+    def rng_stream(self, seed, subsequence, n):
+        out = np.zeros(n, np.uint32)
+        _check(self._lib.pt_rng_stream(self._ctx, seed & 0xFFFFFFFFFFFFFFFF, subsequence, out.ctypes.data, n))
+        return out
+
+    def primary_hits(self, seed, jitter=True):
+        ids = np.zeros((self.height, self.width), np.int32)
+        dist = np.zeros((self.height, self.width), np.float32)
+        _check(self._lib.pt_primary_hits(self._ctx, int(seed), 1 if jitter else 0, ids.ctypes.data, dist.ctypes.data))
+        return ids, dist
+
+    def count_batch(self, seed, current_samples):
+        c = _ffi.CoreCounters()
+        _check(self._lib.pt_count_batch(self._ctx, int(seed), int(current_samples), C.byref(c)))
+        return c.as_dict()
+
+    def last_kernel_ms(self):
+        return float(self._lib.pt_last_kernel_ms(self._ctx))
+
+    def device_footprint(self):
+        return int(self._lib.pt_device_footprint(self._ctx))
+
+    def close(self):
+        if self._ctx:
+            self._lib.pt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

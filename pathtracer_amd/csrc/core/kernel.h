@@ -1,0 +1,730 @@
+// kernel.h — the radiance kernel for gfx950 (wave64).
+//
+// What it computes is render_kernel of the reference (src/renderer.cu:361-405)
+// and everything below it; HOW is different:
+//
+//  * One trace site. The reference nests sample loop > bounce loop > traversal
+//    loop, with separate traversals for the bounce ray, the NEE shadow ray and
+//    one light-pdf ray per emissive LST node. On a 64-wide wave that nesting
+//    leaves most lanes parked at inner reconvergence points. Here every lane
+//    runs a flat state machine whose every iteration ends in the SAME closest-hit
+//    walk; a lane that finishes a path starts its next sample in the next
+//    iteration instead of waiting for the wave. The per-pixel order of RNG
+//    draws is unchanged, so results are too.
+//  * The light-pdf rays of evaluate_direct_p (renderer.cu:251-284) have the same
+//    origin and direction as the next bounce ray (renderer.cu:350-351 ->
+//    :112-117), so their closest hit IS the next bounce's closest hit: one walk
+//    answers all N+1 queries.
+//  * Hit records are built once per path vertex from (face, u, v), not at every
+//    closer hit inside the walk (intersect.cu:100-210).
+//  * Traversal stack: child references (u32) in LDS, [entry][thread] so a wave's
+//    push/pop is one conflict-free ds_write_b32/ds_read_b32.
+//  * The camera basis and 2^exposure are per-launch constants computed on the
+//    host with the reference's operation order (renderer.cu:32-46, :393).
+//
+// Every float operation keeps the reference's association; build with
+// -ffp-contract=off. Doubles appear where the reference's unsuffixed literals
+// promote (SURVEY.md §7 "Hidden double precision").
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "layout.h"
+#include "pt_detmath.h"
+#include "ptcore.h"
+
+namespace ptc {
+
+#define PT_DEV __device__ __forceinline__
+
+struct f3 {
+    float x, y, z;
+};
+PT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+PT_DEV f3 ld3(const float *p) { return f3{p[0], p[1], p[2]}; }
+PT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_DEV float rcp_exact(float s) { return 1.0f / s; } // == (float)(1.0 / (double)s): division is safe under double rounding
+PT_DEV f3 operator/(f3 a, float s) { return a * rcp_exact(s); }
+PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+PT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PT_DEV float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
+PT_DEV f3 normalize(f3 a) { return a * rcp_exact(length(a)); }
+PT_DEV float luminance(f3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
+// glibc fmaxf/fminf selection rules (sign of zero and NaN handling match the host)
+PT_DEV float max_gl(float x, float y) { return (x >= y || y != y) ? x : y; }
+PT_DEV float min_gl(float x, float y) { return (x <= y || y != y) ? x : y; }
+
+// 1e-12 is not a float; these are the float thresholds equivalent to the
+// reference's double compares (intersect.cu:56,65,73; renderer.cu:149).
+#define PT_EPS_UP 1.0000001044244144e-12f /* 0x2b8cbccd: smallest float >= 1e-12 */
+
+struct Texture {
+    const void *texels;
+    int32_t width, height, isFloat, wrapS, wrapT, filter;
+};
+
+struct KernelParams {
+    // geometry
+    const GNode *nodes;
+    const GTri *tris;
+    const GShade *shade;
+    const GMaterial *materials;
+    const pt_light *lights;
+    const pt_lst_node *lst;
+    const Texture *textures;
+    const uint32_t *jump; // [32][160][8] words: XORWOW A^(2^67 * 2^k), rows padded to 8
+    uint32_t root;
+    uint32_t lst_count;
+    int32_t clear_texture;
+    // image
+    int32_t width, height;
+    float clear_color[3];
+    float exposure_scale; // powf(2, exposure)
+    // camera: columns of the basis matrix and the origin (renderer.cu:32-51)
+    float cam_u[3], cam_v[3], cam_w[3], cam_p[3];
+    // launch
+    uint32_t seed_lo, seed_hi;
+    int32_t previous_samples, current_samples;
+    int32_t jitter; // primary-hit probe only
+};
+
+// ---- XORWOW ------------------------------------------------------------------------
+
+struct Rng {
+    uint32_t v0, v1, v2, v3, v4, d;
+    float extra;
+    uint32_t have_extra;
+};
+
+PT_DEV uint32_t rng_next(Rng &s) {
+    uint32_t t = s.v0 ^ (s.v0 >> 2);
+    s.v0 = s.v1;
+    s.v1 = s.v2;
+    s.v2 = s.v3;
+    s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v4 + s.d;
+}
+
+// One 160x160 GF(2) matrix-vector product. The matrix address is wave-uniform,
+// so rows arrive through scalar loads; lanes only differ in the select mask.
+PT_DEV void rng_matvec(const uint32_t *__restrict__ m, uint32_t v[5]) {
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+    for (int i = 0; i < 5; i++) {
+        uint32_t word = v[i];
+#pragma unroll 8
+        for (int j = 0; j < 32; j++) {
+            uint32_t mask = 0u - ((word >> j) & 1u);
+            const uint32_t *row = m + (i * 32 + j) * 8;
+            r0 ^= mask & row[0];
+            r1 ^= mask & row[1];
+            r2 ^= mask & row[2];
+            r3 ^= mask & row[3];
+            r4 ^= mask & row[4];
+        }
+    }
+    v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3; v[4] = r4;
+}
+
+// curand_init(seed, subsequence, 0): scramble, then jump subsequence * 2^67.
+PT_DEV void rng_init(Rng &s, const uint32_t *__restrict__ jump, uint32_t seed_lo, uint32_t seed_hi, uint32_t subsequence) {
+    uint32_t s0 = seed_lo ^ 0xaad26b49u;
+    uint32_t s1 = seed_hi ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    uint32_t v[5];
+    v[0] = 123456789u + t0;
+    v[1] = 362436069u ^ t0;
+    v[2] = 521288629u + t1;
+    v[3] = 88675123u ^ t1;
+    v[4] = 5783321u + t0;
+    s.d = 6615241u + t1 + t0;
+    // Bits that are set in NO lane of the wave are skipped by a uniform branch.
+    for (int k = 0; k < 32; k++) {
+        bool mine = (subsequence >> k) & 1u;
+        if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
+        uint32_t w[5] = {v[0], v[1], v[2], v[3], v[4]};
+        rng_matvec(jump + (size_t)k * 160 * 8, w);
+        if (mine) {
+            v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3]; v[4] = w[4];
+        }
+    }
+    s.v0 = v[0]; s.v1 = v[1]; s.v2 = v[2]; s.v3 = v[3]; s.v4 = v[4];
+    s.extra = 0.f;
+    s.have_extra = 0;
+}
+
+PT_DEV float rng_uniform(Rng &s) { return (float)rng_next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
+
+PT_DEV float rng_normal(Rng &s) {
+    if (s.have_extra) {
+        s.have_extra = 0;
+        return s.extra;
+    }
+    uint32_t x = rng_next(s), y = rng_next(s);
+    const float two_pi_scale = 2.3283064e-10f * 6.2831855f;
+    float u = (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+    float v = (float)y * two_pi_scale + (two_pi_scale / 2.0f);
+    float r = __builtin_sqrtf(-2.0f * pt_logf(u));
+    float sn, cs;
+    pt_sincosf(v, &sn, &cs);
+    s.extra = r * cs;
+    s.have_extra = 1;
+    return r * sn;
+}
+
+// ---- textures ------------------------------------------------------------------------
+
+PT_DEV float wrap_coord(float u, int mode) {
+    if (mode == PT_WRAP_CLAMP) return u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+    if (mode == PT_WRAP_MIRROR) {
+        float t = u - 2.0f * __builtin_floorf(u * 0.5f);
+        return t > 1.0f ? 2.0f - t : t;
+    }
+    return u - __builtin_floorf(u);
+}
+PT_DEV int wrap_index(int i, int n, int mode) {
+    if (mode == PT_WRAP_REPEAT) {
+        i %= n;
+        return i < 0 ? i + n : i;
+    }
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+PT_DEV float4 fetch_texel(const Texture &t, int x, int y) {
+    size_t at = (size_t)y * (size_t)t.width + (size_t)x;
+    if (t.isFloat) return ((const float4 *)t.texels)[at];
+    uchar4 p = ((const uchar4 *)t.texels)[at];
+    return make_float4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
+}
+__device__ __noinline__ float4 sample_texture(const Texture *tp, float u, float v) {
+    Texture t = *tp;
+    float fu = wrap_coord(u, t.wrapS) * (float)t.width;
+    float fv = wrap_coord(v, t.wrapT) * (float)t.height;
+    if (t.filter == PT_FILTER_POINT)
+        return fetch_texel(t, wrap_index((int)__builtin_floorf(fu), t.width, t.wrapS),
+                           wrap_index((int)__builtin_floorf(fv), t.height, t.wrapT));
+    float xb = fu - 0.5f, yb = fv - 0.5f;
+    float x0 = __builtin_floorf(xb), y0 = __builtin_floorf(yb);
+    float a = __builtin_floorf((xb - x0) * 256.0f + 0.5f) / 256.0f;
+    float b = __builtin_floorf((yb - y0) * 256.0f + 0.5f) / 256.0f;
+    int ix0 = wrap_index((int)x0, t.width, t.wrapS), ix1 = wrap_index((int)x0 + 1, t.width, t.wrapS);
+    int iy0 = wrap_index((int)y0, t.height, t.wrapT), iy1 = wrap_index((int)y0 + 1, t.height, t.wrapT);
+    float4 t00 = fetch_texel(t, ix0, iy0), t10 = fetch_texel(t, ix1, iy0);
+    float4 t01 = fetch_texel(t, ix0, iy1), t11 = fetch_texel(t, ix1, iy1);
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float4 r;
+    r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+    r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+    r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+    r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+    return r;
+}
+
+// ---- closest-hit walk ------------------------------------------------------------------
+
+constexpr float kNoHit = 1e30f;
+
+struct HitLite {
+    float t, u, v;
+    int32_t face; // -1: miss
+};
+
+struct Tally {
+    uint32_t samples, rays, inner, tris, walks, shaded, bounces;
+};
+
+// intersect_aabb, src/bvh.cu:222-237 (select forms and tie rules kept)
+PT_DEV float slab(f3 bmin, f3 bmax, f3 o, f3 rinv, float limit) {
+    f3 t1 = (bmin - o) * rinv;
+    f3 t2 = (bmax - o) * rinv;
+    f3 lo = mk3(t1.x < t2.x ? t1.x : t2.x, t1.y < t2.y ? t1.y : t2.y, t1.z < t2.z ? t1.z : t2.z);
+    f3 hi = mk3(t1.x > t2.x ? t1.x : t2.x, t1.y > t2.y ? t1.y : t2.y, t1.z > t2.z ? t1.z : t2.z);
+    float tmin = (lo.x > lo.y && lo.x > lo.z) ? lo.x : (lo.y > lo.z ? lo.y : lo.z);
+    float tmax = (hi.x < hi.y && hi.x < hi.z) ? hi.x : (hi.y < hi.z ? hi.y : hi.z);
+    return (tmax >= tmin && tmin < limit && tmax > 0) ? tmin : kNoHit;
+}
+
+// bvh_intersect_iterative + the triangle half of intersect_face
+// (src/bvh.cu:239-286, src/intersect.cu:12-81, :100). Same visiting order, same
+// strict "closer" test, so exact distance ties resolve to the same face.
+template <bool COUNT, int STACK>
+PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, uint32_t *stack /* &lds[0][tid] */, Tally &n) {
+    HitLite h;
+    h.t = kNoHit;
+    h.u = h.v = 0.f;
+    h.face = -1;
+    f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (COUNT) n.walks++;
+    int sp = 0;
+    uint32_t ref = P.root;
+    for (;;) {
+        if (ref & kLeafBit) {
+            uint32_t first = ref & 0x0FFFFFFFu;
+            uint32_t count = ((ref >> 28) & 7u) + 1;
+            for (uint32_t k = 0; k < count; k++) {
+                const float4 *tp = (const float4 *)(P.tris + first + k);
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+                if (COUNT) n.tris++;
+                f3 pvec = cross(d, e2);
+                float det = dot(e1, pvec);
+                if (det > -PT_EPS_UP && det < PT_EPS_UP) continue;
+                float inv_det = 1.0f / det;
+                f3 tvec = o - v0;
+                float u = dot(tvec, pvec) * inv_det;
+                if (u <= -PT_EPS_UP || u > 1.0f) continue;
+                f3 qvec = cross(tvec, e1);
+                float v = dot(d, qvec) * inv_det;
+                if (v <= -PT_EPS_UP || (u + v) > 1.0f) continue;
+                float t = dot(e2, qvec) * inv_det;
+                if (t >= 0 && t < h.t) {
+                    h.t = t;
+                    h.u = u;
+                    h.v = v;
+                    h.face = (int32_t)__float_as_uint(c.y);
+                }
+            }
+            if (sp == 0) break;
+            ref = stack[(--sp) * 256];
+        } else {
+            const float4 *np = (const float4 *)(P.nodes + ref);
+            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            if (COUNT) n.inner++;
+            float t1 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, h.t);
+            float t2 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, h.t);
+            uint32_t c1 = __float_as_uint(q3.x), c2 = __float_as_uint(q3.y);
+            if (t2 < t1) {
+                uint32_t tc = c1; c1 = c2; c2 = tc;
+                float tt = t1; t1 = t2; t2 = tt;
+            }
+            if (t1 == kNoHit) {
+                if (sp == 0) break;
+                ref = stack[(--sp) * 256];
+            } else {
+                ref = c1;
+                if (t2 != kNoHit) {
+                    if (sp < STACK) stack[sp * 256] = c2; // height is checked at upload; never overflows
+                    sp++;
+                }
+            }
+        }
+    }
+    return h;
+}
+
+// ---- BRDF (src/brdf.cu:3-56, 164-178) ------------------------------------------------------
+
+struct Brdf {
+    f3 baseColor;
+    float roughness, metallic, specular;
+};
+
+PT_DEV float g1_schlick_ggx(float n_dot_v, float roughness) {
+    float alpha = roughness * roughness;
+    float k = 0.5f * alpha; // 0.5 * alpha in double is exact
+    return n_dot_v / (n_dot_v * (1.0f - k) + k);
+}
+
+__device__ __noinline__ f3 brdf_eval(Brdf b, f3 wo, f3 wi) {
+    float cos_theta_wi = max_gl(wi.z, 0.0f);
+    f3 l = wi, v = wo;
+    f3 h = normalize(l + v);
+    float f0d = (float)(0.16 * (double)b.specular * (double)b.specular);
+    f3 F0_diel = mk3(1, 1, 1) * f0d;
+    f3 F0 = (b.baseColor * b.metallic) + (F0_diel * (1 - b.metallic));
+    float x = 1 - dot(v, h);
+    f3 F = F0 + ((((((mk3(1, 1, 1) - F0) * x) * x) * x) * x) * x);
+    float alpha = b.roughness * b.roughness;
+    float bb = h.z * h.z * (alpha * alpha - 1.0f) + 1.0f;
+    float D = alpha * alpha / (PT_PI_F * bb * bb);
+    float G = g1_schlick_ggx(l.z, b.roughness) * g1_schlick_ggx(v.z, b.roughness);
+    float n_dot_v = max_gl(v.z, 0.001f);
+    float n_dot_l = max_gl(l.z, 0.001f);
+    f3 f_spec = ((F * D) * G) / (4.0f * n_dot_v * n_dot_l);
+    f3 f_diff = ((b.baseColor * (mk3(1, 1, 1) - F)) * (float)(1.0 - (double)b.metallic)) * PT_1_PI_F;
+    return (f_diff + f_spec) * cos_theta_wi;
+}
+
+PT_DEV float brdf_pdf() { return 1.0f / (2 * PT_PI_F); }
+
+// rgb_to_radiometric, src/renderer.cu:146-162
+PT_DEV f3 rgb_to_radiometric(f3 color, float intensity) {
+    float m = length(color);
+    f3 cn = mk3(1, 1, 1);
+    if (m >= PT_EPS_UP) cn = color / m;
+    float photometric = intensity * m;
+    float alpha = (float)((double)photometric / (683.0 * (double)luminance(cn)));
+    return cn * alpha;
+}
+
+// ---- the per-lane state machine ------------------------------------------------------------
+
+enum : int { kModeMain = 0, kModeNee = 1 };
+
+struct Vertex { // what survives from a shaded hit until the next main-ray result
+    f3 position, normal; // incident normal
+    f3 tx, ty;           // tangent, bitangent (TBN columns 0 and 1; column 2 = normal)
+    Brdf brdf;
+    f3 wo_ts;
+};
+
+PT_DEV f3 tbn_mul(const Vertex &vx, f3 w) { // hit.tangentBasis * w
+    return mk3((vx.tx.x * w.x + vx.ty.x * w.y) + vx.normal.x * w.z,
+               (vx.tx.y * w.x + vx.ty.y * w.y) + vx.normal.y * w.z,
+               (vx.tx.z * w.x + vx.ty.z * w.y) + vx.normal.z * w.z);
+}
+PT_DEV f3 tbn_t_mul(const Vertex &vx, f3 w) { // transposed basis * w
+    return mk3((vx.tx.x * w.x + vx.tx.y * w.y) + vx.tx.z * w.z,
+               (vx.ty.x * w.x + vx.ty.y * w.y) + vx.ty.z * w.z,
+               (vx.normal.x * w.x + vx.normal.y * w.y) + vx.normal.z * w.z);
+}
+
+// Area-light pdf of a ray that hit `face` at parametric distance t
+// (sample_area_light, src/renderer.cu:98-105,131-133).
+PT_DEV float area_pdf(const GShade *s, f3 dir, float t, f3 *normal_out) {
+    f3 A = ld3(s->pos[0]), B = ld3(s->pos[1]), C = ld3(s->pos[2]);
+    f3 tri_cross = cross(C - B, A - B);
+    float len = length(tri_cross);
+    f3 normal = tri_cross / len;
+    float area = 0.5f * len;
+    float cos_theta_y = __builtin_fabsf(dot(normal, dir));
+    if (normal_out) *normal_out = normal;
+    return t * t / (area * cos_theta_y);
+}
+
+PT_DEV void pixel_of_thread(const KernelParams &P, int *px, int *py) {
+    // 256 threads = a 16x16 pixel block (the reference's block shape,
+    // src/main.cu:85); each wave owns an 8x8 quadrant so its 64 rays stay close.
+    // Blocks sharing blockIdx % 8 share an XCD and its L2, so each residue
+    // class gets one contiguous run of image rows.
+    uint32_t nbx = ((uint32_t)P.width + 15u) / 16u, nby = ((uint32_t)P.height + 15u) / 16u;
+    uint32_t nblocks = nbx * nby;
+    uint32_t b = blockIdx.x, xcd = b % 8u, q = nblocks / 8u, r = nblocks % 8u;
+    uint32_t logical = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
+    uint32_t bx = logical % nbx, by = logical / nbx;
+    uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    *px = (int)(bx * 16u + (wave & 1u) * 8u + (lane & 7u));
+    *py = (int)(by * 16u + (wave >> 1) * 8u + (lane >> 3));
+}
+
+PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {
+    f3 U = ld3(P.cam_u), V = ld3(P.cam_v), W = ld3(P.cam_w);
+    // A * (u, v, 1), A = columns U,V,W (renderer.cu:46-52)
+    f3 a = mk3((U.x * u + V.x * v) + W.x * 1.0f, (U.y * u + V.y * v) + W.y * 1.0f, (U.z * u + V.z * v) + W.z * 1.0f);
+    *o = ld3(P.cam_p);
+    *d = normalize(a);
+}
+
+template <bool COUNT, int STACK>
+__global__ void __launch_bounds__(256) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
+    __shared__ uint32_t lds_stack[STACK * 256];
+    uint32_t *stack = lds_stack + threadIdx.x;
+
+    int px, py;
+    pixel_of_thread(P, &px, &py);
+    bool inside = px < P.width && py < P.height;
+    Tally n = {0, 0, 0, 0, 0, 0, 0};
+
+    Rng rng;
+    rng_init(rng, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(py * P.width + px) : 0u);
+
+    f3 total = mk3(0, 0, 0);
+    f3 light = mk3(0, 0, 0), thr = mk3(1, 1, 1);
+    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+    Vertex vx = {};
+    float rr_prob = 1.f;
+    f3 f_cos_next = mk3(0, 0, 0); // BSDF sample's f*cos, applied once p_direct is known
+    bool pending = false;         // a BSDF sample is waiting for the next hit to finish its MIS weight
+    // NEE state carried across the shadow walk
+    f3 nee_dir = mk3(0, 0, 0), nee_radiance = mk3(0, 0, 0);
+    float nee_p = 0.f, nee_dist = 0.f;
+    int nee_kind = 0; // 0 point, 1 directional, 2 area
+    int nee_face = -1;
+    int mode = kModeMain;
+    int sample = 0;
+    bool need_camera = true;
+    bool alive = inside && P.current_samples > 0;
+
+    while (alive) {
+        if (need_camera) {
+            float sx = (float)px + 0.33f * rng_normal(rng);
+            float sy = (float)py + 0.33f * rng_normal(rng);
+            float u = (2 * sx - (float)P.width) / (float)P.height;
+            float v = (2 * sy - (float)P.height) / (float)P.height;
+            camera_ray(P, u, v, &ro, &rd);
+            light = mk3(0, 0, 0);
+            thr = mk3(1, 1, 1);
+            pending = false;
+            mode = kModeMain;
+            need_camera = false;
+            if (COUNT) n.samples++;
+        }
+
+        HitLite hit = trace<COUNT, STACK>(P, ro, rd, stack, n);
+
+        bool do_bsdf = false;
+        bool end_path = false;
+        if (mode == kModeMain) {
+            if (COUNT) n.rays++;
+            const GShade *sh = hit.face >= 0 ? P.shade + hit.face : nullptr;
+            if (pending) {
+                // evaluate_direct_p: only the LST node whose face this ray hit contributes
+                float p_direct = 0.f;
+                if (P.lst_count != 0) {
+                    if (sh && (sh->flags & kShadeIsLight) && hit.t > 0) {
+                        // a face listed k times in the LST contributes k equal terms
+                        float p_als = area_pdf(sh, rd, hit.t, nullptr);
+                        for (uint32_t k = sh->flags >> 8; k > 0; k--) p_direct += p_als;
+                    }
+                    p_direct = p_direct / (float)P.lst_count;
+                }
+                float pdf = brdf_pdf();
+                float weight = pdf / (p_direct + pdf);
+                thr = thr * (f_cos_next * (weight / (pdf * rr_prob)));
+                pending = false;
+            }
+            if (!sh) {
+                f3 clear = ld3(P.clear_color);
+                if (P.clear_texture >= 0) {
+                    float phi = pt_atan2f(rd.z, rd.x);
+                    float theta = pt_acosf(min_gl(max_gl(rd.y, -1.0f), 1.0f));
+                    float eu = (float)(((double)phi + PT_PI_D) / (2.0f * PT_PI_D));
+                    float ev = (float)((double)theta / PT_PI_D);
+                    float4 t = sample_texture(P.textures + P.clear_texture, eu, ev);
+                    clear = clear * mk3(t.x, t.y, t.z);
+                }
+                light = light + thr * clear;
+                end_path = true;
+            } else {
+                // ---- hit record (intersect.cu:100-198) ----
+                GShade s = *sh;
+                GMaterial m = P.materials[s.material];
+                float u = hit.u, v = hit.v;
+                float w = (float)(1.0 - (double)u - (double)v);
+                f3 position = (w * ld3(s.pos[0]) + u * ld3(s.pos[1])) + v * ld3(s.pos[2]);
+                f3 baseColor = mk3(m.baseColorFactor[0], m.baseColorFactor[1], m.baseColorFactor[2]);
+                float alpha = m.baseColorFactor[3];
+                float roughness = m.roughness, metallic = m.metallic;
+                if (m.baseColorTexture >= 0 || m.metallicRoughnessTexture >= 0) {
+                    float tu = (w * s.uv[0][0] + u * s.uv[1][0]) + v * s.uv[2][0];
+                    float tv = (w * s.uv[0][1] + u * s.uv[1][1]) + v * s.uv[2][1];
+                    if (m.baseColorTexture >= 0) {
+                        float4 t = sample_texture(P.textures + m.baseColorTexture, tu, tv);
+                        baseColor = baseColor * mk3(t.x, t.y, t.z);
+                        alpha *= t.w;
+                    }
+                    if (m.metallicRoughnessTexture >= 0) {
+                        float4 t = sample_texture(P.textures + m.metallicRoughnessTexture, tu, tv);
+                        roughness *= t.y;
+                        metallic *= t.z;
+                    }
+                }
+                if (m.alphaMode == PT_ALPHA_OPAQUE) alpha = 1.0f;
+                else if (m.alphaMode == PT_ALPHA_MASK) alpha = alpha > m.alphaCutoff ? 1.0f : 0.0f;
+
+                f3 normal, tangent;
+                if (s.flags & kShadeFlat) {
+                    normal = ld3(s.nrm[0]);
+                    tangent = ld3(s.tan[0]);
+                } else {
+                    normal = (w * ld3(s.nrm[0]) + u * ld3(s.nrm[1])) + v * ld3(s.nrm[2]);
+                    tangent = (w * ld3(s.tan[0]) + u * ld3(s.tan[1])) + v * ld3(s.tan[2]);
+                }
+                float handed = s.handed < 0 ? -1.0f : 1.0f;
+                f3 bitangent = handed * cross(normal, tangent);
+                tangent = normalize(tangent);
+                bitangent = normalize(bitangent);
+                normal = normalize(normal);
+                if (dot(normal, rd) > 0) {
+                    tangent = tangent * -1.0f;
+                    bitangent = bitangent * -1.0f;
+                    normal = normal * -1.0f;
+                }
+
+                // ---- integrate_Li body (renderer.cu:309-355) ----
+                if (rng_uniform(rng) >= alpha) {
+                    ro = position + 1e-6f * (-normal);
+                    // direction unchanged; no RR, no throughput change (renderer.cu:310-314)
+                } else {
+                    if (COUNT) n.shaded++;
+                    light = light + ld3(m.emissive) * thr;
+                    rr_prob = min_gl(luminance(thr), 0.99f);
+                    if (rng_uniform(rng) >= rr_prob) {
+                        end_path = true;
+                    } else {
+                        vx.position = position;
+                        vx.normal = normal;
+                        vx.tx = tangent;
+                        vx.ty = bitangent;
+                        vx.brdf.baseColor = baseColor;
+                        vx.brdf.roughness = roughness;
+                        vx.brdf.metallic = metallic;
+                        vx.brdf.specular = m.specular;
+                        vx.wo_ts = tbn_t_mul(vx, -rd);
+
+                        // ---- sample_light_source (renderer.cu:164-249) up to the shadow walk ----
+                        if (P.lst_count == 0) {
+                            do_bsdf = true;
+                        } else {
+                            int node_index = (int)((float)P.lst_count * rng_uniform(rng));
+                            pt_lst_node node = P.lst[(uint32_t)node_index % P.lst_count];
+                            nee_p = 1.0f / (float)P.lst_count;
+                            if (node.type == PT_LST_SOURCE_LIGHT) {
+                                const pt_light *L = P.lights + node.index;
+                                f3 lcolor = mk3(L->color.x, L->color.y, L->color.z);
+                                if (L->type == PT_LIGHT_POINT) {
+                                    f3 dl = mk3(L->position.x, L->position.y, L->position.z) - position;
+                                    float distance = length(dl);
+                                    nee_dir = dl / distance;
+                                    nee_dist = distance;
+                                    nee_kind = 0;
+                                    f3 radiant_intensity = rgb_to_radiometric(lcolor, L->intensity);
+                                    nee_radiance = radiant_intensity / (distance * distance);
+                                } else {
+                                    nee_dir = normalize(-mk3(L->direction.x, L->direction.y, L->direction.z));
+                                    nee_kind = 1;
+                                    nee_radiance = rgb_to_radiometric(lcolor, L->intensity);
+                                }
+                            } else {
+                                const GShade *ls = P.shade + node.index;
+                                f3 A = ld3(ls->pos[0]), B = ld3(ls->pos[1]), C = ld3(ls->pos[2]);
+                                float u1, u2;
+                                do {
+                                    u1 = rng_uniform(rng);
+                                    u2 = rng_uniform(rng);
+                                } while (u1 + u2 > 1);
+                                f3 light_pos = (A + u1 * (B - A)) + u2 * (C - A);
+                                nee_dir = normalize(light_pos - position);
+                                nee_kind = 2;
+                                nee_face = (int)node.index;
+                                nee_radiance = rgb_to_radiometric(ld3(P.materials[ls->material].emissive), 1.0f);
+                            }
+                            ro = position + 1e-6f * normal;
+                            rd = nee_dir;
+                            mode = kModeNee;
+                        }
+                    }
+                }
+            }
+        } else {
+            // ---- shadow walk finished: visibility + MIS-weighted direct light ----
+            if (COUNT) n.rays++;
+            float p_lss = nee_p;
+            if (nee_kind == 0) {
+                if (!(nee_dist < hit.t)) p_lss = 0;
+            } else if (nee_kind == 1) {
+                if (hit.face >= 0) p_lss = 0;
+            } else {
+                bool visible = hit.face >= 0 && hit.t > 0 && hit.face == nee_face;
+                float p_als = 0.f;
+                if (visible) p_als = area_pdf(P.shade + nee_face, nee_dir, hit.t, nullptr);
+                p_lss = visible ? p_lss * p_als : 0.f;
+            }
+            if (p_lss > 0) {
+                f3 l_ts = tbn_t_mul(vx, nee_dir);
+                float p_brdf = brdf_pdf();
+                f3 f_cos = brdf_eval(vx.brdf, vx.wo_ts, l_ts);
+                f3 direct = f_cos * nee_radiance;
+                float weight = p_lss / (p_lss + p_brdf);
+                light = light + ((weight / p_lss) * thr) * direct;
+            }
+            do_bsdf = true;
+        }
+
+        if (do_bsdf) {
+            // BRDF::sample (brdf.cu:180-192) + next ray (renderer.cu:345-350)
+            f3 r;
+            do {
+                r.x = 2 * rng_uniform(rng) - 1;
+                r.y = 2 * rng_uniform(rng) - 1;
+                r.z = 2 * rng_uniform(rng) - 1;
+            } while (dot(r, r) > 1);
+            f3 wi = normalize(r);
+            wi.z = __builtin_fabsf(wi.z);
+            f_cos_next = brdf_eval(vx.brdf, vx.wo_ts, wi);
+            if (COUNT) {
+                n.bounces++;
+                // the reference walks the BVH once per emissive LST node for the pdf
+                for (uint32_t i = 0; i < P.lst_count; i++)
+                    if (P.lst[i].type == PT_LST_SOURCE_FACE) n.rays++;
+            }
+            rd = tbn_mul(vx, wi);
+            ro = vx.position + 1e-6f * vx.normal;
+            pending = true;
+            mode = kModeMain;
+        }
+
+        if (end_path) {
+            total = total + light;
+            sample++;
+            need_camera = true;
+            if (sample >= P.current_samples) alive = false;
+        }
+    }
+
+    if (inside) {
+        total = total * P.exposure_scale;
+        total = total / (float)P.current_samples;
+        int total_samples = P.previous_samples + P.current_samples;
+        float *p = img + 3 * ((size_t)py * (size_t)P.width + (size_t)px);
+        if (img) {
+            f3 last = mk3(p[0], p[1], p[2]);
+            f3 next = last * ((float)P.previous_samples / (float)total_samples) +
+                      total * ((float)P.current_samples / (float)total_samples);
+            p[0] = next.x;
+            p[1] = next.y;
+            p[2] = next.z;
+        }
+    }
+    if (COUNT && counters) {
+        atomicAdd(&counters[0], (unsigned long long)n.samples);
+        atomicAdd(&counters[1], (unsigned long long)n.rays);
+        atomicAdd(&counters[2], (unsigned long long)n.inner);
+        atomicAdd(&counters[3], (unsigned long long)n.tris);
+        atomicAdd(&counters[4], (unsigned long long)n.walks);
+        atomicAdd(&counters[5], (unsigned long long)n.shaded);
+        atomicAdd(&counters[6], (unsigned long long)n.bounces);
+    }
+}
+
+// First camera ray of every pixel: face id + distance (parity probe).
+template <int STACK>
+__global__ void __launch_bounds__(256) primary_hits_kernel(KernelParams P, int32_t *__restrict__ faces, float *__restrict__ dist) {
+    __shared__ uint32_t lds_stack[STACK * 256];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    int px, py;
+    pixel_of_thread(P, &px, &py);
+    bool inside = px < P.width && py < P.height;
+    Rng rng;
+    rng_init(rng, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(py * P.width + px) : 0u);
+    if (!inside) return;
+    float nx = rng_normal(rng), ny = rng_normal(rng);
+    if (!P.jitter) nx = ny = 0;
+    float sx = (float)px + 0.33f * nx, sy = (float)py + 0.33f * ny;
+    float u = (2 * sx - (float)P.width) / (float)P.height;
+    float v = (2 * sy - (float)P.height) / (float)P.height;
+    f3 o, d;
+    camera_ray(P, u, v, &o, &d);
+    Tally n = {0, 0, 0, 0, 0, 0, 0};
+    HitLite h = trace<false, STACK>(P, o, d, stack, n);
+    size_t at = (size_t)py * (size_t)P.width + (size_t)px;
+    faces[at] = h.face;
+    if (dist) dist[at] = h.t;
+}
+
+__global__ void rng_stream_kernel(const uint32_t *jump, uint32_t seed_lo, uint32_t seed_hi, uint32_t subsequence,
+                                  uint32_t *out, int count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Rng rng;
+    rng_init(rng, jump, seed_lo, seed_hi, subsequence);
+    for (int i = 0; i < count; i++) out[i] = rng_next(rng);
+}
+
+} // namespace ptc

@@ -1,0 +1,217 @@
+// layout.h — device-side records and the host-side baker that produces them.
+//
+// The reference keeps array-of-struct scene data on the device and chases
+// indices -> faces -> vertices per triangle test (5 dependent loads,
+// src/bvh.cu:253-255, src/intersect.cu:85-98) and node -> 2 child nodes per inner
+// visit (3 dependent 40 B loads, src/bvh.cu:258-262). Here every step of the walk
+// is ONE aligned record:
+//
+//   GNode     64 B  both children's boxes + both child references. One inner
+//                   visit = one 64 B fetch (4 x dwordx4), no second hop.
+//   GTri      48 B  v0, e1 = v1-v0, e2 = v2-v0, face id; stored in leaf order so a
+//                   leaf's triangles are contiguous. e1/e2 are the float
+//                   differences the reference recomputes per test
+//                   (intersect.cu:19-20), so the arithmetic downstream is
+//                   unchanged.
+//   GShade   144 B  everything intersect_face reads to build the hit record
+//                   (positions, normals, tangents, uvs, handedness, material),
+//                   indexed by the ORIGINAL face index; fetched once per shaded
+//                   hit instead of once per closer hit.
+//   GMaterial 64 B  the material fields the kernel reads.
+//
+// Child reference: bit 31 set = leaf, bits 30..28 = triangle count - 1,
+// bits 27..0 = first triangle; bit 31 clear = index of a GNode.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_types.h"
+
+namespace ptc {
+
+struct alignas(16) GNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    uint32_t left, right;
+    uint32_t pad[2];
+};
+static_assert(sizeof(GNode) == 64, "GNode must be one 64-byte line");
+
+struct alignas(16) GTri {
+    float v0[3], e1[3], e2[3];
+    uint32_t face;
+    uint32_t pad[2];
+};
+static_assert(sizeof(GTri) == 48, "GTri is three 16-byte loads");
+
+enum : uint32_t { kShadeFlat = 1u, kShadeIsLight = 2u };
+
+struct alignas(16) GShade {
+    float pos[3][3];
+    float nrm[3][3];
+    float tan[3][3];
+    float uv[3][2];
+    float handed;      // A.tangent.w (or face.tangent.w when flat)
+    uint32_t material;
+    uint32_t flags;    // kShadeFlat | kShadeIsLight | (times listed in the LST) << 8
+};
+static_assert(sizeof(GShade) == 144, "GShade is nine 16-byte loads");
+
+struct alignas(16) GMaterial {
+    float baseColorFactor[4];
+    float emissive[3];
+    float specular;
+    float metallic, roughness, alphaCutoff;
+    uint32_t alphaMode;
+    int32_t baseColorTexture, normalTexture, metallicRoughnessTexture;
+    uint32_t pad;
+};
+static_assert(sizeof(GMaterial) == 64, "GMaterial is four 16-byte loads");
+
+struct GTexture {
+    const void *texels; // device pointer, RGBA float or RGBA8
+    int32_t width, height;
+    int32_t isFloat;
+    int32_t wrapS, wrapT, filter;
+};
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kMaxLeafTris = 8;
+constexpr uint32_t kMaxTris = 1u << 28;
+
+inline uint32_t leaf_ref(uint32_t first_tri, uint32_t count) { return kLeafBit | ((count - 1) << 28) | first_tri; }
+
+struct BakedBvh {
+    std::vector<GNode> nodes;
+    std::vector<GTri> tris;
+    uint32_t root = 0; // child reference of the root
+    int height = 0;    // nodes on the longest root-to-leaf path
+};
+
+// Converts the reference-format BVH. Returns "" or an error message.
+// Triangle positions come from the baked shading records (the library's own
+// copy of the scene), so the caller's scene arrays need not outlive the upload.
+inline std::string bake_bvh(const std::vector<GShade> &shade, const pt_bvh_node *nodes, uint32_t node_count,
+                            const uint32_t *indices, uint32_t index_count, BakedBvh &out) {
+    if (node_count == 0) return "BVH has no nodes";
+    if (index_count > kMaxTris) return "BVH references more than 2^28 triangles";
+    out.nodes.clear();
+    out.tris.clear();
+    out.tris.reserve(index_count);
+
+    // Triangles in `indices` order: leaf [start, end) -> GTri [start, end).
+    for (uint32_t i = 0; i < index_count; i++) {
+        uint32_t f = indices[i];
+        if (f >= shade.size()) return "BVH index list references face " + std::to_string(f) + " past the scene";
+        const float *a = shade[f].pos[0], *b = shade[f].pos[1], *c = shade[f].pos[2];
+        GTri t;
+        memset(&t, 0, sizeof(t));
+        t.v0[0] = a[0]; t.v0[1] = a[1]; t.v0[2] = a[2];
+        t.e1[0] = b[0] - a[0]; t.e1[1] = b[1] - a[1]; t.e1[2] = b[2] - a[2];
+        t.e2[0] = c[0] - a[0]; t.e2[1] = c[1] - a[1]; t.e2[2] = c[2] - a[2];
+        t.face = f;
+        out.tris.push_back(t);
+    }
+
+    auto is_leaf = [&](const pt_bvh_node &n) { return n.end - n.start > 0; };
+    auto make_leaf = [&](const pt_bvh_node &n, uint32_t *ref) -> std::string {
+        uint32_t count = n.end - n.start;
+        if (n.end > index_count || n.start >= n.end) return "leaf range outside the index list";
+        if (count > kMaxLeafTris) return "leaf with " + std::to_string(count) + " faces (at most 8 supported)";
+        *ref = leaf_ref(n.start, count);
+        return "";
+    };
+
+    if (is_leaf(nodes[0])) {
+        out.height = 1;
+        return make_leaf(nodes[0], &out.root);
+    }
+
+    // Inner nodes keep the reference's numbering order (dense remap).
+    std::vector<uint32_t> remap(node_count, 0xFFFFFFFFu);
+    uint32_t inner = 0;
+    for (uint32_t i = 0; i < node_count; i++)
+        if (!is_leaf(nodes[i])) remap[i] = inner++;
+    out.nodes.resize(inner);
+    for (uint32_t i = 0; i < node_count; i++) {
+        const pt_bvh_node &n = nodes[i];
+        if (is_leaf(n)) continue;
+        if (n.leftChild >= node_count || n.rightChild >= node_count) return "child index outside the node array";
+        if (n.leftChild <= i || n.rightChild <= i) return "child index does not follow its parent (cycle?)";
+        GNode g;
+        memset(&g, 0, sizeof(g));
+        const pt_bvh_node &l = nodes[n.leftChild], &r = nodes[n.rightChild];
+        g.lmin[0] = l.bmin.x; g.lmin[1] = l.bmin.y; g.lmin[2] = l.bmin.z;
+        g.lmax[0] = l.bmax.x; g.lmax[1] = l.bmax.y; g.lmax[2] = l.bmax.z;
+        g.rmin[0] = r.bmin.x; g.rmin[1] = r.bmin.y; g.rmin[2] = r.bmin.z;
+        g.rmax[0] = r.bmax.x; g.rmax[1] = r.bmax.y; g.rmax[2] = r.bmax.z;
+        std::string err;
+        if (is_leaf(l)) err = make_leaf(l, &g.left); else g.left = remap[n.leftChild];
+        if (!err.empty()) return err;
+        if (is_leaf(r)) err = make_leaf(r, &g.right); else g.right = remap[n.rightChild];
+        if (!err.empty()) return err;
+        out.nodes[remap[i]] = g;
+    }
+    out.root = 0;
+
+    // Height (children follow parents, so one reverse sweep suffices).
+    std::vector<int> h(inner, 1);
+    int height = 1;
+    for (uint32_t k = inner; k-- > 0;) {
+        const GNode &g = out.nodes[k];
+        int hl = (g.left & kLeafBit) ? 1 : h[g.left];
+        int hr = (g.right & kLeafBit) ? 1 : h[g.right];
+        h[k] = 1 + (hl > hr ? hl : hr);
+    }
+    height = h[0];
+    out.height = height;
+    return "";
+}
+
+inline void bake_shading(const pt_scene_desc &scene, std::vector<GShade> &shade, std::vector<GMaterial> &mats) {
+    shade.resize(scene.face_count);
+    for (uint32_t f = 0; f < scene.face_count; f++) {
+        const pt_face &face = scene.faces[f];
+        GShade s;
+        memset(&s, 0, sizeof(s));
+        for (int k = 0; k < 3; k++) {
+            const pt_vertex &v = scene.vertices[face.vertices[k]];
+            s.pos[k][0] = v.position.x; s.pos[k][1] = v.position.y; s.pos[k][2] = v.position.z;
+            s.nrm[k][0] = v.normal.x;   s.nrm[k][1] = v.normal.y;   s.nrm[k][2] = v.normal.z;
+            s.tan[k][0] = v.tangent.x;  s.tan[k][1] = v.tangent.y;  s.tan[k][2] = v.tangent.z;
+            s.uv[k][0] = v.texcoord0.x; s.uv[k][1] = v.texcoord0.y;
+        }
+        s.handed = scene.vertices[face.vertices[0]].tangent.w;
+        if (face.shading == PT_FLAT_SHADING) {
+            s.flags |= kShadeFlat;
+            s.nrm[0][0] = face.normal.x;  s.nrm[0][1] = face.normal.y;  s.nrm[0][2] = face.normal.z;
+            s.tan[0][0] = face.tangent.x; s.tan[0][1] = face.tangent.y; s.tan[0][2] = face.tangent.z;
+            s.handed = face.tangent.w;
+        }
+        s.material = face.material;
+        shade[f] = s;
+    }
+    mats.resize(scene.material_count);
+    for (uint32_t m = 0; m < scene.material_count; m++) {
+        const pt_material &src = scene.materials[m];
+        GMaterial g;
+        memset(&g, 0, sizeof(g));
+        g.baseColorFactor[0] = src.baseColorFactor.x; g.baseColorFactor[1] = src.baseColorFactor.y;
+        g.baseColorFactor[2] = src.baseColorFactor.z; g.baseColorFactor[3] = src.baseColorFactor.w;
+        g.emissive[0] = src.emissive.x; g.emissive[1] = src.emissive.y; g.emissive[2] = src.emissive.z;
+        g.specular = src.specular;
+        g.metallic = src.metallicFactor;
+        g.roughness = src.roughnessFactor;
+        g.alphaCutoff = src.alphaCutoff;
+        g.alphaMode = src.alphaMode;
+        g.baseColorTexture = src.baseColorTexture;
+        g.normalTexture = src.normalTexture;
+        g.metallicRoughnessTexture = src.metallicRoughnessTexture;
+        mats[m] = g;
+    }
+}
+
+} // namespace ptc

@@ -1,0 +1,505 @@
+// ptcore.hip — C ABI of include/ptcore.h over the kernels in kernel.h.
+// gfx950 only; no CUDA-compat headers, no dual paths.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernel.h"
+#include "layout.h"
+#include "ptcore.h"
+
+using namespace ptc;
+
+namespace {
+
+thread_local char g_error[1024] = "";
+
+int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail("HIP error: %s (%s)", hipGetErrorString(e_), #expr); \
+    } while (0)
+
+template <typename T> struct DeviceArray {
+    T *ptr = nullptr;
+    size_t count = 0;
+    size_t bytes() const { return count * sizeof(T); }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    int upload(const T *src, size_t n) {
+        release();
+        count = n;
+        size_t sz = (n ? n : 1) * sizeof(T); // never a null device pointer
+        HIP_TRY(hipMalloc((void **)&ptr, sz));
+        if (n) HIP_TRY(hipMemcpy(ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+
+// ---- XORWOW jump tables (host) ------------------------------------------------------
+// A = one xorshift step on the 160-bit state; table k = A^(2^67 * 2^k), stored as
+// [bit][8] words (5 used): the image of each input bit. Built by repeated squaring.
+
+void xorwow_step(uint32_t v[5]) {
+    uint32_t t = v[0] ^ (v[0] >> 2);
+    v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = v[4];
+    v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+}
+
+struct BitMatrix {
+    uint32_t col[160][5];
+    void apply(const uint32_t in[5], uint32_t out[5]) const {
+        uint32_t r[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < 160; b++)
+            if (in[b >> 5] & (1u << (b & 31)))
+                for (int k = 0; k < 5; k++) r[k] ^= col[b][k];
+        memcpy(out, r, sizeof(r));
+    }
+    void square() {
+        BitMatrix next;
+        for (int b = 0; b < 160; b++) apply(col[b], next.col[b]);
+        *this = next;
+    }
+};
+
+constexpr int kJumpTables = 32; // subsequence = y*W + x < 2^32
+
+std::vector<uint32_t> build_jump_tables() {
+    BitMatrix m;
+    for (int b = 0; b < 160; b++) {
+        uint32_t v[5] = {0, 0, 0, 0, 0};
+        v[b >> 5] = 1u << (b & 31);
+        xorwow_step(v);
+        memcpy(m.col[b], v, sizeof(v));
+    }
+    for (int s = 0; s < 67; s++) m.square();
+    std::vector<uint32_t> out((size_t)kJumpTables * 160 * 8, 0u);
+    for (int k = 0; k < kJumpTables; k++) {
+        for (int b = 0; b < 160; b++) memcpy(&out[((size_t)k * 160 + (size_t)b) * 8], m.col[b], 5 * sizeof(uint32_t));
+        m.square();
+    }
+    return out;
+}
+
+// ---- host float helpers with the reference's operation order (camera basis) ------------
+
+struct H3 {
+    float x, y, z;
+};
+H3 hsub(H3 a, H3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+H3 hcross(H3 a, H3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+float hdot(H3 a, H3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+H3 hscale(H3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+H3 hunit(H3 a) { return hscale(a, (float)(1.0 / (double)sqrtf(hdot(a, a)))); }
+
+} // namespace
+
+struct pt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+
+    // host copies needed across uploads
+    std::vector<GShade> h_shade;
+    std::vector<uint32_t> h_light_mult; // per face: times listed in the LST
+
+    DeviceArray<GNode> nodes;
+    DeviceArray<GTri> tris;
+    DeviceArray<GShade> shade;
+    DeviceArray<GMaterial> materials;
+    DeviceArray<pt_light> lights;
+    DeviceArray<pt_lst_node> lst;
+    DeviceArray<Texture> textures;
+    std::vector<void *> texel_blocks;
+    size_t texel_bytes = 0;
+    DeviceArray<uint32_t> jump;
+    DeviceArray<float> image;
+    DeviceArray<unsigned long long> counters;
+
+    bool have_scene = false, have_bvh = false, have_lst = false, have_cfg = false;
+    uint32_t face_count = 0, light_count = 0;
+    int bvh_height = 0;
+    KernelParams P{};
+};
+
+namespace {
+
+int bind(pt_context *ctx) {
+    if (!ctx) return fail("null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return 0;
+}
+
+int ready(pt_context *ctx) {
+    if (bind(ctx)) return 1;
+    if (!ctx->have_scene) return fail("pt_scene_upload has not been called");
+    if (!ctx->have_bvh) return fail("pt_bvh_upload has not been called");
+    if (!ctx->have_lst) return fail("pt_lst_upload has not been called");
+    if (!ctx->have_cfg) return fail("pt_configure has not been called");
+    return 0;
+}
+
+void set_launch(pt_context *ctx, int seed, int prev, int cur, int jitter) {
+    uint64_t s = (uint64_t)(int64_t)seed; // config_t::seed is int, widened to uint64_t (renderer.cu:374)
+    ctx->P.seed_lo = (uint32_t)s;
+    ctx->P.seed_hi = (uint32_t)(s >> 32);
+    ctx->P.previous_samples = prev;
+    ctx->P.current_samples = cur;
+    ctx->P.jitter = jitter;
+}
+
+dim3 grid_of(const pt_context *ctx) {
+    uint32_t nbx = ((uint32_t)ctx->P.width + 15u) / 16u, nby = ((uint32_t)ctx->P.height + 15u) / 16u;
+    return dim3(nbx * nby);
+}
+
+template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned long long *counters, hipStream_t st) {
+    dim3 grid = grid_of(ctx), block(256);
+    if (ctx->bvh_height <= 33)
+        hipLaunchKernelGGL((render_kernel<COUNT, 32>), grid, block, 0, st, ctx->P, img, counters);
+    else
+        hipLaunchKernelGGL((render_kernel<COUNT, 64>), grid, block, 0, st, ctx->P, img, counters);
+}
+
+} // namespace
+
+extern "C" const char *pt_last_error(void) { return g_error; }
+
+extern "C" int pt_create(int device, pt_context **out) {
+    if (!out) return fail("pt_create: null output pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail("pt_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail("pt_create: device %d out of range (0..%d)", device, ndev - 1);
+    pt_context *ctx = new pt_context();
+    ctx->device = device;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ctx->ev_start));
+    HIP_TRY(hipEventCreate(&ctx->ev_stop));
+    std::vector<uint32_t> tables = build_jump_tables();
+    if (ctx->jump.upload(tables.data(), tables.size())) return 1;
+    unsigned long long zeros[8] = {0};
+    if (ctx->counters.upload(zeros, 8)) return 1;
+    ctx->P.jump = ctx->jump.ptr;
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void pt_destroy(pt_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->nodes.release();
+    ctx->tris.release();
+    ctx->shade.release();
+    ctx->materials.release();
+    ctx->lights.release();
+    ctx->lst.release();
+    ctx->textures.release();
+    for (void *p : ctx->texel_blocks) (void)hipFree(p);
+    ctx->jump.release();
+    ctx->image.release();
+    ctx->counters.release();
+    (void)hipEventDestroy(ctx->ev_start);
+    (void)hipEventDestroy(ctx->ev_stop);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int pt_scene_upload(pt_context *ctx, const pt_scene_desc *scene) {
+    if (bind(ctx)) return 1;
+    if (!scene) return fail("pt_scene_upload: null scene");
+    if (scene->face_count == 0 || !scene->faces || !scene->vertices) return fail("pt_scene_upload: scene has no faces");
+    for (uint32_t f = 0; f < scene->face_count; f++) {
+        const pt_face &face = scene->faces[f];
+        if (face.vertexCount != 3) return fail("pt_scene_upload: face %u has %u vertices (triangles only)", f, face.vertexCount);
+        for (int k = 0; k < 3; k++)
+            if (face.vertices[k] >= scene->vertex_count)
+                return fail("pt_scene_upload: face %u references vertex %u of %u", f, face.vertices[k], scene->vertex_count);
+        if (face.material >= scene->material_count)
+            return fail("pt_scene_upload: face %u references material %u of %u", f, face.material, scene->material_count);
+    }
+    for (uint32_t m = 0; m < scene->material_count; m++) {
+        const pt_material &mat = scene->materials[m];
+        int32_t t[3] = {mat.baseColorTexture, mat.normalTexture, mat.metallicRoughnessTexture};
+        for (int k = 0; k < 3; k++)
+            if (t[k] >= (int32_t)scene->texture_count)
+                return fail("pt_scene_upload: material %u references texture %d of %u", m, t[k], scene->texture_count);
+    }
+    if (scene->clearTexture >= (int32_t)scene->texture_count)
+        return fail("pt_scene_upload: clearTexture %d of %u", scene->clearTexture, scene->texture_count);
+
+    std::vector<GMaterial> mats;
+    bake_shading(*scene, ctx->h_shade, mats);
+    ctx->h_light_mult.assign(scene->face_count, 0);
+    if (ctx->shade.upload(ctx->h_shade.data(), ctx->h_shade.size())) return 1;
+    if (ctx->materials.upload(mats.data(), mats.size())) return 1;
+    if (ctx->lights.upload(scene->lights, scene->light_count)) return 1;
+
+    for (void *p : ctx->texel_blocks) (void)hipFree(p);
+    ctx->texel_blocks.clear();
+    ctx->texel_bytes = 0;
+    std::vector<Texture> tex(scene->texture_count);
+    for (uint32_t i = 0; i < scene->texture_count; i++) {
+        const pt_texture &src = scene->textures[i];
+        if (src.width <= 0 || src.height <= 0 || !src.pixels || src.channels != 4)
+            return fail("pt_scene_upload: texture %u is empty or not 4-channel", i);
+        size_t bytes = (size_t)src.width * (size_t)src.height * 4 * (src.isFloat ? sizeof(float) : 1);
+        void *d = nullptr;
+        HIP_TRY(hipMalloc(&d, bytes));
+        ctx->texel_blocks.push_back(d);
+        ctx->texel_bytes += bytes;
+        HIP_TRY(hipMemcpy(d, src.pixels, bytes, hipMemcpyHostToDevice));
+        tex[i].texels = d;
+        tex[i].width = src.width;
+        tex[i].height = src.height;
+        tex[i].isFloat = src.isFloat;
+        tex[i].wrapS = src.wrapS;
+        tex[i].wrapT = src.wrapT;
+        tex[i].filter = src.filter;
+    }
+    if (ctx->textures.upload(tex.data(), tex.size())) return 1;
+
+    // camera basis, renderer.cu:32-46 (depends only on the camera, so once per scene)
+    const pt_camera &cam = scene->camera;
+    H3 Pp{cam.position.x, cam.position.y, cam.position.z}, T{cam.target.x, cam.target.y, cam.target.z};
+    H3 Up{cam.updir.x, cam.updir.y, cam.updir.z};
+    H3 W = hsub(T, Pp);
+    H3 U = hcross(W, Up);
+    H3 V = hcross(U, W);
+    float focal = 0.1f;
+    float yheight = atanf((float)(0.5 * (double)cam.yfov)) * focal;
+    U = hscale(hunit(U), yheight);
+    V = hscale(hunit(V), yheight);
+    W = hscale(hunit(W), focal);
+    KernelParams &P = ctx->P;
+    P.cam_u[0] = U.x; P.cam_u[1] = U.y; P.cam_u[2] = U.z;
+    P.cam_v[0] = V.x; P.cam_v[1] = V.y; P.cam_v[2] = V.z;
+    P.cam_w[0] = W.x; P.cam_w[1] = W.y; P.cam_w[2] = W.z;
+    P.cam_p[0] = Pp.x; P.cam_p[1] = Pp.y; P.cam_p[2] = Pp.z;
+    P.shade = ctx->shade.ptr;
+    P.materials = ctx->materials.ptr;
+    P.lights = ctx->lights.ptr;
+    P.textures = ctx->textures.ptr;
+    P.clear_texture = scene->clearTexture;
+    ctx->face_count = scene->face_count;
+    ctx->light_count = scene->light_count;
+    ctx->have_scene = true;
+    ctx->have_bvh = false; // a BVH belongs to one scene
+    ctx->have_lst = false;
+    return 0;
+}
+
+extern "C" int pt_bvh_upload(pt_context *ctx, const pt_bvh_node *nodes, uint32_t node_count, const uint32_t *indices,
+                             uint32_t index_count) {
+    if (bind(ctx)) return 1;
+    if (!ctx->have_scene) return fail("pt_bvh_upload: call pt_scene_upload first");
+    if (!nodes || !indices) return fail("pt_bvh_upload: null argument");
+    BakedBvh baked;
+    std::string err = bake_bvh(ctx->h_shade, nodes, node_count, indices, index_count, baked);
+    if (!err.empty()) return fail("pt_bvh_upload: %s", err.c_str());
+    // the reference refuses trees taller than its 64-entry stack (bvh.cu:338-342)
+    if (baked.height > 65) return fail("pt_bvh_upload: tree height %d exceeds the 64-entry traversal stack", baked.height);
+    if (ctx->nodes.upload(baked.nodes.data(), baked.nodes.size())) return 1;
+    if (ctx->tris.upload(baked.tris.data(), baked.tris.size())) return 1;
+    ctx->P.nodes = ctx->nodes.ptr;
+    ctx->P.tris = ctx->tris.ptr;
+    ctx->P.root = baked.root;
+    ctx->bvh_height = baked.height;
+    ctx->have_bvh = true;
+    return 0;
+}
+
+extern "C" int pt_lst_upload(pt_context *ctx, const pt_lst_node *nodes, uint32_t count) {
+    if (bind(ctx)) return 1;
+    if (!ctx->have_scene) return fail("pt_lst_upload: call pt_scene_upload first");
+    if (count && !nodes) return fail("pt_lst_upload: null argument");
+    std::vector<uint32_t> mult(ctx->face_count, 0);
+    for (uint32_t i = 0; i < count; i++) {
+        if (nodes[i].type == PT_LST_SOURCE_FACE) {
+            if (nodes[i].index >= ctx->face_count) return fail("pt_lst_upload: node %u references face %u", i, nodes[i].index);
+            mult[nodes[i].index]++;
+        } else if (nodes[i].type == PT_LST_SOURCE_LIGHT) {
+            if (nodes[i].index >= ctx->light_count) return fail("pt_lst_upload: node %u references light %u", i, nodes[i].index);
+        } else {
+            return fail("pt_lst_upload: node %u has unknown type %u", i, nodes[i].type);
+        }
+    }
+    for (uint32_t f = 0; f < ctx->face_count; f++) {
+        uint32_t flags = ctx->h_shade[f].flags & kShadeFlat;
+        if (mult[f]) flags |= kShadeIsLight | (mult[f] << 8);
+        ctx->h_shade[f].flags = flags;
+    }
+    if (ctx->shade.upload(ctx->h_shade.data(), ctx->h_shade.size())) return 1;
+    ctx->P.shade = ctx->shade.ptr;
+    if (ctx->lst.upload(nodes, count)) return 1;
+    ctx->P.lst = ctx->lst.ptr;
+    ctx->P.lst_count = count;
+    ctx->have_lst = true;
+    return 0;
+}
+
+extern "C" int pt_configure(pt_context *ctx, const pt_render_config *cfg) {
+    if (bind(ctx)) return 1;
+    if (!cfg) return fail("pt_configure: null config");
+    if (cfg->resolution_x <= 0 || cfg->resolution_y <= 0) return fail("pt_configure: empty image");
+    if ((uint64_t)cfg->resolution_x * (uint64_t)cfg->resolution_y > 0xFFFFFFFFull)
+        return fail("pt_configure: more than 2^32 pixels");
+    KernelParams &P = ctx->P;
+    P.width = cfg->resolution_x;
+    P.height = cfg->resolution_y;
+    P.clear_color[0] = cfg->world_clear_color.x;
+    P.clear_color[1] = cfg->world_clear_color.y;
+    P.clear_color[2] = cfg->world_clear_color.z;
+    P.exposure_scale = powf(2.0f, cfg->output_exposure); // renderer.cu:393
+    size_t n = (size_t)P.width * (size_t)P.height * 3;
+    if (ctx->image.count != n) {
+        ctx->image.release();
+        ctx->image.count = n;
+        HIP_TRY(hipMalloc((void **)&ctx->image.ptr, n * sizeof(float)));
+    }
+    HIP_TRY(hipMemset(ctx->image.ptr, 0, n * sizeof(float)));
+    ctx->have_cfg = true;
+    return 0;
+}
+
+extern "C" int pt_clear_image(pt_context *ctx) {
+    if (bind(ctx)) return 1;
+    if (!ctx->have_cfg) return fail("pt_clear_image: pt_configure has not been called");
+    HIP_TRY(hipMemsetAsync(ctx->image.ptr, 0, ctx->image.bytes(), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int pt_render_batch_into(pt_context *ctx, float *device_img, void *stream, int seed, int previous_samples,
+                                    int current_samples) {
+    if (ready(ctx)) return 1;
+    if (!device_img) return fail("pt_render_batch_into: null image");
+    if (current_samples <= 0 || previous_samples < 0) return fail("pt_render_batch: bad sample counts (%d, %d)", previous_samples, current_samples);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    set_launch(ctx, seed, previous_samples, current_samples, 1);
+    HIP_TRY(hipEventRecord(ctx->ev_start, st));
+    launch_render<false>(ctx, device_img, nullptr, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_stop, st));
+    ctx->timed = true;
+    return 0;
+}
+
+extern "C" int pt_render_batch(pt_context *ctx, int seed, int previous_samples, int current_samples) {
+    if (ready(ctx)) return 1;
+    if (pt_render_batch_into(ctx, ctx->image.ptr, nullptr, seed, previous_samples, current_samples)) return 1;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int pt_synchronize(pt_context *ctx) {
+    if (bind(ctx)) return 1;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" float pt_last_kernel_ms(pt_context *ctx) {
+    if (!ctx || !ctx->timed) return -1.f;
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1.f;
+    if (hipEventSynchronize(ctx->ev_stop) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop) != hipSuccess) return -1.f;
+    return ms;
+}
+
+extern "C" int pt_read_image(pt_context *ctx, float *host_rgb) {
+    if (bind(ctx)) return 1;
+    if (!ctx->have_cfg) return fail("pt_read_image: pt_configure has not been called");
+    if (!host_rgb) return fail("pt_read_image: null buffer");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(host_rgb, ctx->image.ptr, ctx->image.bytes(), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int pt_rng_stream(pt_context *ctx, uint64_t seed, uint64_t subsequence, uint32_t *host_out, int n) {
+    if (bind(ctx)) return 1;
+    if (!host_out || n <= 0) return fail("pt_rng_stream: bad arguments");
+    if (subsequence > 0xFFFFFFFFull) return fail("pt_rng_stream: subsequence beyond 2^32 (pixel indices are 32-bit)");
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (size_t)n * sizeof(uint32_t)));
+    hipLaunchKernelGGL(rng_stream_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->jump.ptr, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), (uint32_t)subsequence, d, n);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(host_out, d, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail("HIP error: %s (pt_rng_stream)", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int pt_primary_hits(pt_context *ctx, int seed, int jitter, int32_t *host_face_ids, float *host_distances) {
+    if (ready(ctx)) return 1;
+    if (!host_face_ids) return fail("pt_primary_hits: null buffer");
+    size_t n = (size_t)ctx->P.width * (size_t)ctx->P.height;
+    int32_t *d_faces = nullptr;
+    float *d_dist = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_faces, n * sizeof(int32_t)));
+    hipError_t e = hipMalloc((void **)&d_dist, n * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(d_faces);
+        return fail("HIP error: %s (pt_primary_hits)", hipGetErrorString(e));
+    }
+    set_launch(ctx, seed, 0, 1, jitter);
+    if (ctx->bvh_height <= 33)
+        hipLaunchKernelGGL((primary_hits_kernel<32>), grid_of(ctx), dim3(256), 0, ctx->stream, ctx->P, d_faces, d_dist);
+    else
+        hipLaunchKernelGGL((primary_hits_kernel<64>), grid_of(ctx), dim3(256), 0, ctx->stream, ctx->P, d_faces, d_dist);
+    e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(host_face_ids, d_faces, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && host_distances) e = hipMemcpy(host_distances, d_dist, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_faces);
+    (void)hipFree(d_dist);
+    if (e != hipSuccess) return fail("HIP error: %s (pt_primary_hits)", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt_counters *out) {
+    if (ready(ctx)) return 1;
+    if (!out || current_samples <= 0) return fail("pt_count_batch: bad arguments");
+    HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, ctx->counters.bytes(), ctx->stream));
+    set_launch(ctx, seed, 0, current_samples, 1);
+    launch_render<true>(ctx, nullptr, ctx->counters.ptr, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpy(h, ctx->counters.ptr, sizeof(h), hipMemcpyDeviceToHost));
+    out->samples = h[0];
+    out->rays = h[1];
+    out->inner_visits = h[2];
+    out->tri_tests = h[3];
+    out->traversals = h[4];
+    out->shaded_hits = h[5];
+    out->bounces = h[6];
+    return 0;
+}
+
+extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
+    if (!ctx) return 0;
+    return ctx->nodes.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
+           ctx->lst.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes();
+}

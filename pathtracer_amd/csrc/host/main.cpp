@@ -1,0 +1,152 @@
+// main.cpp — bin/pathtracer: the reference's CLI (src/main.cu:36-156) on top of the C ABIs.
+//
+// Same flags (src/config.cu:63-83), same outputs (<dir-output>/log.txt and render.png,
+// rewritten after every batch), same batch loop (seed + 1 per batch, running mean) and the
+// same "Rendered a out of b S/px in t s - x S/px/s - y MS/s" line, whose clock — like the
+// reference's — includes the device->host copy and the PNG encode of every batch
+// (main.cu:98,116-131). The kernel-only rate is logged next to it. Exit-on-error policy as in
+// the reference (utils.cu:16-22).
+#include <sys/stat.h>
+#include <sys/types.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ptcore.h"
+#include "pthost.h"
+
+static void human_readable_size(char *buf, size_t n, unsigned long long bytes) { // utils.cu:24-35
+    if (bytes < 1000ull) snprintf(buf, n, "%lluB", bytes);
+    else if (bytes < 1000000ull) snprintf(buf, n, "%lluKB", bytes / 1000ull);
+    else if (bytes < 1000000000ull) snprintf(buf, n, "%lluMB", bytes / 1000000ull);
+    else snprintf(buf, n, "%lluGB", bytes / 1000000000ull);
+}
+
+#define CORE_TRY(call)                                              \
+    do {                                                            \
+        if (call) {                                                 \
+            fprintf(stderr, "HIP error: %s\n", pt_last_error());    \
+            pth_log(1, "%s\n", pt_last_error());                    \
+            exit(EXIT_FAILURE);                                     \
+        }                                                           \
+    } while (0)
+
+int main(int argc, char *argv[]) {
+    printf("Reading config from args: ");
+    for (int i = 0; i < argc; i++) printf("%s ", argv[i]);
+    printf("\n\n");
+
+    pth_config cfg;
+    pth_load_config(&cfg, argc, argv);
+    if (cfg.resolution_x <= 0 || cfg.resolution_y <= 0 || cfg.samples <= 0 || cfg.samples_every_update <= 0 ||
+        !cfg.path_gltf[0] || !cfg.dir_output[0]) {
+        fprintf(stderr, "missing or invalid required flags (resolution, samples, --path-gltf, --dir-output)\n");
+        return 1;
+    }
+
+    struct stat st;
+    if (stat(cfg.dir_output, &st) == -1) mkdir(cfg.dir_output, 0700);
+    char log_file[PTH_PATH_MAX + 16];
+    snprintf(log_file, sizeof(log_file), "%s/log.txt", cfg.dir_output);
+    snprintf(cfg.path_render, sizeof(cfg.path_render), "%.240s/render.png", cfg.dir_output);
+    if (pth_log_init(cfg.log_level, log_file, cfg.log_stdout)) return 1;
+
+    pth_scene *scene = nullptr;
+    if (pth_scene_load_gltf(cfg.path_gltf, &cfg, &scene)) {
+        fprintf(stderr, "%s\n", pth_last_error());
+        return EXIT_FAILURE;
+    }
+    const pt_scene_desc *desc = pth_scene_get_desc(scene);
+
+    pth_log(3, "Building BVH...  \n");
+    pth_bvh bvh;
+    if (pth_bvh_build(desc, &bvh)) {
+        pth_log(1, "%s\n", pth_last_error());
+        return EXIT_FAILURE;
+    }
+    pth_log(3, "Done building BVH\n");
+
+    pth_log(3, "Building LST... \n");
+    pt_lst_node *lst = nullptr;
+    uint32_t lst_count = 0;
+    if (pth_lst_build(desc, &lst, &lst_count)) {
+        pth_log(1, "%s\n", pth_last_error());
+        return EXIT_FAILURE;
+    }
+    pth_log(3, "Done building LST\n");
+
+    size_t pixels = (size_t)cfg.resolution_x * (size_t)cfg.resolution_y;
+    std::vector<float> h_img(pixels * 3);
+
+    // ########## DISPATCH #############
+    int device = 0;
+    if (const char *env = getenv("PT_DEVICE")) device = atoi(env);
+    pt_context *ctx = nullptr;
+    CORE_TRY(pt_create(device, &ctx));
+    char buf[64];
+    pth_log(3, "Copying scene to device... \n");
+    CORE_TRY(pt_scene_upload(ctx, desc));
+    unsigned long long after_scene = pt_device_footprint(ctx);
+    human_readable_size(buf, sizeof(buf), after_scene);
+    pth_log(3, "Done [%s]\n", buf);
+    pth_log(3, "Copying bvh_t to device... \n");
+    CORE_TRY(pt_bvh_upload(ctx, bvh.nodes, bvh.node_count, bvh.indices, bvh.index_count));
+    unsigned long long after_bvh = pt_device_footprint(ctx);
+    human_readable_size(buf, sizeof(buf), after_bvh - after_scene);
+    pth_log(3, "Done [%s]\n", buf);
+    pth_log(3, "Copying lst_t to device... \n");
+    CORE_TRY(pt_lst_upload(ctx, lst, lst_count));
+    human_readable_size(buf, sizeof(buf), (unsigned long long)lst_count * sizeof(pt_lst_node));
+    pth_log(3, "Done [%s]\n", buf);
+
+    pt_render_config rc;
+    rc.resolution_x = cfg.resolution_x;
+    rc.resolution_y = cfg.resolution_y;
+    rc.output_exposure = cfg.output_exposure;
+    rc.world_clear_color = cfg.world_clear_color;
+    CORE_TRY(pt_configure(ctx, &rc));
+
+    pth_log(3, "Launching kernel... \n");
+    pth_log(3, "Rendering %d samples in batches of %d, img size (%d, %d)\n", cfg.samples, cfg.samples_every_update,
+            cfg.resolution_x, cfg.resolution_y);
+    pth_log(3, "Kernel params <<<(%d), (256)>>> (16x16-pixel blocks, one 8x8 tile per wave64)\n",
+            ((cfg.resolution_x + 15) / 16) * ((cfg.resolution_y + 15) / 16));
+
+    auto start = std::chrono::system_clock::now();
+    double kernel_seconds = 0;
+    int rendered = 0;
+    while (rendered < cfg.samples) {
+        int current = cfg.samples_every_update < cfg.samples - rendered ? cfg.samples_every_update : cfg.samples - rendered;
+        CORE_TRY(pt_render_batch(ctx, cfg.seed, rendered, current));
+        kernel_seconds += pt_last_kernel_ms(ctx) / 1000.0;
+        CORE_TRY(pt_read_image(ctx, h_img.data()));
+        if (pth_write_image(h_img.data(), cfg.resolution_x, cfg.resolution_y, cfg.path_render)) {
+            pth_log(1, "%s\n", pth_last_error());
+            exit(EXIT_FAILURE);
+        }
+        rendered += current;
+
+        auto now = std::chrono::system_clock::now();
+        int elapsed_ms = (int)std::chrono::duration_cast<std::chrono::milliseconds>(now - start).count();
+        float elapsed = elapsed_ms / 1000.0f;
+        cfg.seed++;
+        float ms_per_s = (float)cfg.resolution_x * cfg.resolution_y * rendered / (1000000.0 * elapsed);
+        float spp_per_s = rendered / elapsed;
+        pth_log(3, "Rendered %d out of %d S/px in %.1fs - %.2f S/px/s - %.2f MS/s\n", rendered, cfg.samples, elapsed,
+                spp_per_s, ms_per_s);
+        pth_log(3, "Kernel only: %.3fs - %.2f MS/s\n", kernel_seconds,
+                (double)pixels * rendered / (1e6 * (kernel_seconds > 0 ? kernel_seconds : 1e-9)));
+        pth_log(4, "Updated image: %s\n", cfg.path_render);
+    }
+    // ########## DISPATCH #############
+
+    pt_destroy(ctx);
+    pth_free(lst);
+    pth_bvh_free(&bvh);
+    pth_scene_free(scene);
+    pth_log_close();
+    return 0;
+}

@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of the radiance kernel on the many_lights configuration.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one launch of the hot path over one batch: 1024x1024 pixels x 50 spp of the
+many_lights STAND-IN scene (the reference's many_lights.bin does not ship; the stand-in has the
+same room, lights, emitter, camera, materials and a 322 792-triangle mesh in the scan's bounds —
+pathtracer_amd/scenes.py). K=4 is the README run (200 spp in batches of 50, seed 42). Inputs are
+resident in HBM before the timed region. With N > 1 (one rank per GPU, launched by
+torch.distributed.run) every rank renders K batches of its own (weak scaling), batch b = j*N + rank
+seeded 42 + b, and the per-rank accumulators are combined by ONE RCCL sum all-reduce inside the
+timed region.
+
+Rank 0 prints one JSON line with the throughput, a roofline object for the dominant kernel
+(algorithmic bytes from the instrumented kernel variant / HIP-event launch time) and a
+cpu_baseline object (the CPU oracle timed on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH = HEIGHT = 1024
+SPP_PER_STEP = 50
+SEED = 42
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(c, width, height):
+    """64 B per inner-node visit (two child boxes + two references), 40 B per
+    triangle test (positions + id), 240 B per shaded hit (face + 3 x (normal, tangent, uv) +
+    material), 24 B per pixel per launch (accumulator read + write)."""
+    return 64 * c["inner_visits"] + 40 * c["tri_tests"] + 240 * c["shaded_hits"] + 24 * width * height
+
+
+def cpu_baseline(scene, bvh, lst, threads):
+    """The oracle ("port") on 128 image rows x 1024 px x 50 spp of the same workload."""
+    from oracle import binding as ob
+    import numpy as np
+    o = ob.Oracle(scene, bvh, lst, WIDTH, HEIGHT)
+    rows = (HEIGHT // 2 - 64, HEIGHT // 2 + 64)
+    img = np.zeros((HEIGHT, WIDTH, 3), np.float32)
+    t0 = time.perf_counter()
+    _, ctr = o.render_batch(SEED, 0, SPP_PER_STEP, img, threads=threads, rows=rows)
+    dt = time.perf_counter() - t0
+    return {"value": round(ctr["samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"rows {rows[0]}..{rows[1] - 1} of the same 1024x1024x50spp batch "
+                      f"({ctr['samples']} samples, {ctr['rays']} rays, {dt:.2f} s wall)",
+            "mrays_per_s": round(ctr["rays"] / dt / 1e6, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from pathtracer_amd import core, host, render, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- inputs (host pipeline; not timed) ----------------------------------------------
+    with tempfile.TemporaryDirectory() as d:
+        scene = host.Scene.load_gltf(scenes.write_many_lights_standin(d))
+    bvh, lst = host.BVH(scene), host.LST(scene)
+    r = core.Renderer(local_rank)
+    r.upload(scene, bvh, lst)
+    r.configure(WIDTH, HEIGHT, 0.0, (0.0, 0.0, 0.0))
+    acc = torch.zeros(WIDTH * HEIGHT * 3, dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ---- warmup ----------------------------------------------------------------------------
+    for i in range(args.warmup):
+        r.render_batch_into(acc.data_ptr(), SEED + 1000 + i, 0, SPP_PER_STEP, stream)
+    if world > 1:
+        dist.all_reduce(acc)
+    acc.zero_()
+    barrier()
+
+    # ---- timed region: K batches per rank + one reduce ---------------------------------------
+    kernel_ms = []
+    t0 = time.perf_counter()
+    prev = 0
+    for j in range(args.steps):
+        b = j * world + rank
+        r.render_batch_into(acc.data_ptr(), SEED + b, prev, SPP_PER_STEP, stream)
+        prev += SPP_PER_STEP
+        kernel_ms.append(r.last_kernel_ms())  # waits for that launch (HIP events on its stream)
+    render.combine(acc, prev, prev * world)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    finite = bool(torch.isfinite(acc).all().item())
+    mean = float(acc.mean().item())
+
+    if rank == 0:
+        spp_total = SPP_PER_STEP * args.steps * world
+        samples = WIDTH * HEIGHT * spp_total
+        counters = r.count_batch(SEED, SPP_PER_STEP)  # instrumented variant, first timed batch, untimed
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        abytes = algorithmic_bytes(counters, WIDTH, HEIGHT)
+        achieved = abytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Msamples/s (node) many_lights 1024x1024x200spp", "value": round(samples / elapsed / 1e6, 3),
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "many_lights STAND-IN (room+point+sun+emitter, 322804 tris) 1024x1024, "
+                                   f"{SPP_PER_STEP} spp per step, seed 42+batch", "resolution": [WIDTH, HEIGHT],
+                       "spp_per_step": SPP_PER_STEP, "spp_total": spp_total, "parallelism": f"sample-shard x{world}",
+                       "bvh_nodes": int(bvh.node_count), "faces": int(len(scene.faces)), "lst_nodes": int(len(lst.nodes))},
+            "kernel_ms_per_step": round(avg_ms, 3),
+            "kernel_msamples_per_s": round(WIDTH * HEIGHT * SPP_PER_STEP / (avg_ms * 1e-3) / 1e6, 3),
+            "mrays_per_s": round(counters["rays"] / (avg_ms * 1e-3) / 1e6 * world, 2),
+            "mtraversals_per_s": round(counters["traversals"] / (avg_ms * 1e-3) / 1e6 * world, 2),
+            "counters_per_step": counters,
+            "image_finite": finite, "image_mean": round(mean, 6),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "render_kernel<false,32>", "algorithmic_bytes_per_launch": int(abytes)},
+        }
+        if not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+            out["cpu_baseline"] = cpu_baseline(scene, bvh, lst, threads)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

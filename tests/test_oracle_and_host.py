@@ -1,0 +1,492 @@
+"""CPU tests: the oracle against its pins, the host pipeline, and the C ABI surface.
+
+None of these needs a GPU. Tests that read /root/reference skip when it is not mounted (the GPU
+box); everything they establish is also carried by the committed fixtures in tests/golden/.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from pathtracer_amd import _ffi, host, scenes
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASSETS = "/root/reference/assets"
+needs_reference = pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference tree not mounted")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ---- RNG -------------------------------------------------------------------------------------
+
+def _xorwow_python(state, n):
+    v = [int(x) for x in state[:5]]
+    d = int(state[5])
+    out = []
+    M = 0xFFFFFFFF
+    for _ in range(n):
+        t = v[0] ^ (v[0] >> 2)
+        v = v[1:] + [((v[4] ^ ((v[4] << 4) & M)) ^ (t ^ ((t << 1) & M))) & M]
+        d = (d + 362437) & M
+        out.append((v[4] + d) & M)
+    return out
+
+
+def test_xorwow_step_matches_plain_python():
+    """The published XORWOW recurrence (identical in rocRAND, rocrand_xorwow.h:165-177)."""
+    for seed, sub in ((42, 0), (43, 1), (7, 65535)):
+        st = ob.rng_state(seed, sub)
+        assert [int(x) for x in ob.rng_stream(seed, sub, 32)] == _xorwow_python(st, 32)
+
+
+def test_seed_scramble_subsequence_zero():
+    """curand_init(seed, 0, 0): the scramble alone (constants as recalled in SURVEY.md §8c)."""
+    M = 0xFFFFFFFF
+    for seed in (0, 42, 2 ** 40 + 5):
+        s0 = (seed & M) ^ 0xaad26b49
+        s1 = (seed >> 32) ^ 0xf7dcefdd
+        t0 = (1099087573 * s0) & M
+        t1 = (2591861531 * s1) & M
+        want = [(123456789 + t0) & M, 362436069 ^ t0, (521288629 + t1) & M, 88675123 ^ t1, (5783321 + t0) & M,
+                (6615241 + t1 + t0) & M]
+        assert [int(x) for x in ob.rng_state(seed, 0)] == want
+
+
+def _rocrand_sequence_tables():
+    path = "/opt/rocm/include/rocrand/rocrand_xorwow_precomputed.h"
+    if not os.path.exists(path):
+        pytest.skip("rocRAND headers not installed")
+    text = open(path).read()
+    start = text.index("h_xorwow_sequence_jump_matrices")
+    body = text[text.index("{", start):]
+    nums = re.findall(r"\b\d+U?\b", body[:body.index("};")])
+    vals = np.array([int(n.rstrip("U")) for n in nums], dtype=np.uint64).astype(np.uint32)
+    assert vals.size == 32 * 800
+    return vals.reshape(32, 800)
+
+
+def test_jump_matrices_match_rocrand_tables():
+    """A^(2^67 * 4^k): our repeated-squaring result equals rocRAND's precomputed tables."""
+    tables = _rocrand_sequence_tables()
+    for k in (0, 1, 2, 5, 10, 15):
+        assert np.array_equal(ob.sequence_jump_matrix(k), tables[k]), k
+
+
+def test_subsequence_is_a_jump_of_2_pow_67_steps_structure():
+    """Jumping by subsequence a then b equals jumping by a+b (group structure of the matrices)."""
+    tables = _rocrand_sequence_tables()
+
+    def apply(m, v):
+        r = np.zeros(5, np.uint32)
+        for i in range(5):
+            for j in range(32):
+                if (int(v[i]) >> j) & 1:
+                    r ^= m[(i * 32 + j) * 5:(i * 32 + j) * 5 + 5]
+        return r
+
+    base = ob.rng_state(42, 0)
+    one = ob.rng_state(42, 1)
+    assert np.array_equal(apply(tables[0], base[:5]), one[:5]) and base[5] == one[5]
+    five = ob.rng_state(42, 5)  # 5 = 1 + 4 -> tables[0] then tables[1]
+    assert np.array_equal(apply(tables[1], apply(tables[0], base[:5])), five[:5])
+
+
+def test_rng_golden_vectors():
+    g = json.load(open(os.path.join(util.GOLDEN, "oracle_c1.json")))
+    assert [int(x) for x in ob.rng_stream(42, 0, 8)] == g["rng_first8_seed42_sub0"]
+    assert [int(x) for x in ob.rng_stream(42, 65535, 8)] == g["rng_first8_seed42_sub65535"]
+    assert [int(x) for x in ob.rng_stream(43, 1, 8)] == g["rng_first8_seed43_sub1"]
+
+
+# ---- deterministic math --------------------------------------------------------------------------
+
+def _ulp_err(got, want):
+    want32 = want.astype(np.float32)
+    ulp = np.spacing(np.abs(want32)).astype(np.float64)
+    return np.abs(got.astype(np.float64) - want) / np.maximum(ulp, 1e-45)
+
+
+def test_detmath_accuracy():
+    L = ob.lib()
+    rng = np.random.RandomState(0)
+    u = ((rng.randint(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.float32)) * np.float32(2.3283064e-10)
+         + np.float32(2.3283064e-10 / 2))
+    got = np.array([L.orc_logf(float(x)) for x in u], np.float32)
+    # compare where |log| is not tiny (relative ulp near log(1)=0 is meaningless)
+    big = np.abs(np.log(u.astype(np.float64))) > 1e-3
+    assert _ulp_err(got[big], np.log(u.astype(np.float64))[big]).max() <= 4
+    ang = rng.uniform(0, 2 * np.pi, 20000).astype(np.float32)
+    s, c = C.c_float(), C.c_float()
+    err = 0.0
+    for a in ang:
+        L.orc_sincosf(float(a), C.byref(s), C.byref(c))
+        err = max(err, abs(s.value - np.sin(float(a))), abs(c.value - np.cos(float(a))))
+    assert err < 3e-7
+    xs = rng.uniform(-1, 1, 5000).astype(np.float32)
+    assert max(abs(L.orc_acosf(float(x)) - np.arccos(float(x))) for x in xs) < 1e-6
+    ys = rng.uniform(-2, 2, 5000).astype(np.float32)
+    assert max(abs(L.orc_atan2f(float(y), float(x)) - np.arctan2(float(y), float(x))) for x, y in zip(xs, ys)) < 1e-6
+    assert L.orc_atan2f(0.0, 0.0) == 0.0
+
+
+# ---- host pipeline pins ------------------------------------------------------------------------------
+
+@needs_reference
+@pytest.mark.parametrize("name", ["cornell", "glass_mirror", "dragon"])
+def test_scene_and_bvh_counts_match_survey(name):
+    """Vertex/face/material counts, BVH node count and height equal what SURVEY.md §3.3/§8 recorded
+    from the reference's own loader and builder; digests equal the committed fixture."""
+    stats = json.load(open(os.path.join(util.GOLDEN, "scene_stats.json")))[name]
+    s = host.Scene.load_gltf(f"{ASSETS}/{name}.gltf")
+    b = host.BVH(s)
+    sv = stats["survey"]
+    assert len(s.vertices) == sv["vertices"] and len(s.faces) == sv["faces"] and len(s.materials) == sv["materials"]
+    assert b.node_count == sv["node_count"] and b.stats["max_depth"] == sv["max_depth"]
+    assert b.node_capacity == 2 * sv["faces"] - 1
+    ours = stats["ours"]
+    assert sha(s.vertices) == ours["vertices_sha256"] and sha(s.faces) == ours["faces_sha256"]
+    assert sha(b.nodes) == ours["nodes_sha256"] and sha(b.indices) == ours["indices_sha256"]
+
+
+@needs_reference
+def test_many_lights_materials_match_example_log():
+    """example_output/.../log.txt:2-41 lists the parsed materials of many_lights.gltf (names,
+    emissive 5,5,5 for EMIT, roughness 0.5): the JSON ships even though the .bin does not."""
+    doc = json.load(open(f"{ASSETS}/many_lights.gltf"))
+    names = [m["name"] for m in doc["materials"]]
+    assert names == ["WHITE", "RED", "BLUE", "WHITE.001", "EMIT"]
+    log = open("/root/reference/example_output/20260111_192720/many_lights/log.txt").read()
+    assert "Emissive: (5.00, 5.00, 5.00)" in log and log.count("Roughness: 0.50") == 5
+
+
+def test_bvh_invariants_and_parallel_build_identical(scene_dir):
+    path = scenes.write_many_lights_standin(scene_dir, name="ml_small", rings=120, segments=300)
+    s = host.Scene.load_gltf(path)
+    os.environ["PTH_BUILD_THREADS"] = "1"
+    b1 = host.BVH(s)
+    n1, i1 = b1.nodes.copy(), b1.indices.copy()
+    os.environ["PTH_BUILD_THREADS"] = "8"
+    b8 = host.BVH(s)
+    os.environ.pop("PTH_BUILD_THREADS")
+    assert len(s.faces) >= 65536  # the threaded path is taken
+    assert np.array_equal(n1, b8.nodes) and np.array_equal(i1, b8.indices)
+    nodes = b8.nodes
+    leaf = (nodes["end"] - nodes["start"]) > 0
+    assert ((nodes["end"] - nodes["start"])[leaf] <= 2).all()
+    assert sorted(b8.indices.tolist()) == list(range(len(s.faces)))
+    inner = np.where(~leaf)[0]
+    assert (nodes["leftChild"][inner] > inner).all() and (nodes["rightChild"][inner] == nodes["leftChild"][inner] + 1).all()
+    # every child box lies inside its parent's box
+    for i in inner[:2000]:
+        for c in (nodes["leftChild"][i], nodes["rightChild"][i]):
+            assert (nodes["bmin"][c] >= nodes["bmin"][i]).all() and (nodes["bmax"][c] <= nodes["bmax"][i]).all()
+    assert leaf.sum() == b8.stats["number_leaves"]
+
+
+def test_lst_lists_emissive_faces_then_lights(scene_dir):
+    s = host.Scene.load_gltf(scenes.write_many_lights_standin(scene_dir, name="ml_tiny", rings=8, segments=8))
+    lst = host.LST(s).nodes
+    emissive = [i for i, f in enumerate(s.faces) if s.materials[f["material"]]["emissive"].max() > 0]
+    assert lst["type"].tolist() == [0] * len(emissive) + [1, 1]
+    assert lst["index"].tolist() == emissive + [0, 1]
+    assert s.lights["type"].tolist() == [1, 0]  # point, then directional (node order)
+
+
+# ---- tangents against the vendored MikkTSpace C library ------------------------------------------------
+
+class _MikkInterface(C.Structure):
+    _fields_ = [("getNumFaces", C.c_void_p), ("getNumVerticesOfFace", C.c_void_p), ("getPosition", C.c_void_p),
+                ("getNormal", C.c_void_p), ("getTexCoord", C.c_void_p), ("setTSpaceBasic", C.c_void_p),
+                ("setTSpace", C.c_void_p)]
+
+
+class _MikkContext(C.Structure):
+    _fields_ = [("interface", C.POINTER(_MikkInterface)), ("userdata", C.c_void_p)]
+
+
+def _reference_tangents(vertices, faces):
+    """Runs genTangSpaceDefault from oracle/_ref/libmikkref.so with the reference's callbacks
+    (src/scene.cu:381-447): write through the index list, w = -sign."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libmikkref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libmikkref.so not built (reference tree absent at build time)")
+    lib = C.CDLL(so)
+    v = vertices.copy()
+    fv = faces["vertices"]
+    I32, PF = C.c_int32, C.POINTER(C.c_float)
+    nf = C.CFUNCTYPE(I32, C.c_void_p)(lambda ctx: len(faces))
+    nv = C.CFUNCTYPE(I32, C.c_void_p, I32)(lambda ctx, f: 3)
+
+    def getter(field, n):
+        def fn(ctx, out, f, i):
+            src = v[field][fv[f][i]]
+            for k in range(n):
+                out[k] = float(src[k])
+        return C.CFUNCTYPE(None, C.c_void_p, PF, I32, I32)(fn)
+
+    gp, gn, gt = getter("position", 3), getter("normal", 3), getter("texcoord0", 2)
+
+    def setter(ctx, tan, sign, f, i):
+        v["tangent"][fv[f][i]] = (tan[0], tan[1], tan[2], -sign)
+
+    st = C.CFUNCTYPE(None, C.c_void_p, PF, C.c_float, I32, I32)(setter)
+    iface = _MikkInterface(C.cast(nf, C.c_void_p), C.cast(nv, C.c_void_p), C.cast(gp, C.c_void_p),
+                           C.cast(gn, C.c_void_p), C.cast(gt, C.c_void_p), C.cast(st, C.c_void_p), None)
+    ctx = _MikkContext(C.pointer(iface), None)
+    lib.genTangSpaceDefault.argtypes = [C.POINTER(_MikkContext)]
+    assert lib.genTangSpaceDefault(C.byref(ctx)) == 1
+    return v
+
+
+def _mesh_arrays(path):
+    s = host.Scene.load_gltf(path)
+    return s.vertices.copy(), s.faces.copy()
+
+
+def _check_tangents(vertices, faces):
+    ours = vertices.copy()
+    ours["tangent"] = 0
+    host.calculate_tangents(ours, faces)
+    ref = vertices.copy()
+    ref["tangent"] = 0
+    ref = _reference_tangents(ref, faces)
+    assert np.array_equal(ours["tangent"].view(np.uint32), ref["tangent"].view(np.uint32))
+
+
+def test_tangents_match_mikktspace_blob(scene_dir):
+    v, f = _mesh_arrays(scenes.write_cornell_like(scene_dir, name="tan_blob", detail=10))
+    _check_tangents(v, f)
+
+
+def test_tangents_match_mikktspace_degenerate_and_mirrored():
+    """Coinciding positions (set-aside triangles), zero uv area (group-with-any), mirrored uvs."""
+    rng = np.random.RandomState(3)
+    n = 40
+    v = np.zeros(n, _ffi.VERTEX_DTYPE)
+    v["position"] = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    nr = rng.normal(size=(n, 3))
+    v["normal"] = (nr / np.linalg.norm(nr, axis=1, keepdims=True)).astype(np.float32)
+    v["texcoord0"][:, :2] = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    v["position"][5] = v["position"][4]          # degenerate triangle below
+    v["texcoord0"][10:14] = v["texcoord0"][10]   # zero uv area
+    tris = [(0, 1, 2), (2, 1, 3), (4, 5, 6), (6, 5, 7), (10, 11, 12), (12, 11, 13), (0, 2, 8), (8, 2, 9),
+            (20, 21, 22), (22, 21, 23), (23, 21, 24), (3, 1, 25), (30, 31, 32), (32, 31, 30)]
+    f = np.zeros(len(tris), _ffi.FACE_DTYPE)
+    f["vertices"] = np.array(tris, np.uint32)
+    f["vertexCount"] = 3
+    f["shading"] = 1
+    _check_tangents(v, f)
+
+
+def test_tangents_without_uv_are_default():
+    """uv == 0 everywhere (dragon): every vertex keeps (1,0,0) with w = +1."""
+    v = np.zeros(4, _ffi.VERTEX_DTYPE)
+    v["position"] = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]])
+    v["normal"] = np.float32([0, 0, 1])
+    f = np.zeros(2, _ffi.FACE_DTYPE)
+    f["vertices"] = [(0, 1, 2), (2, 1, 3)]
+    f["vertexCount"] = 3
+    host.calculate_tangents(v, f)
+    assert np.array_equal(v["tangent"], np.tile(np.float32([1, 0, 0, 1]), (4, 1)))
+
+
+@needs_reference
+def test_tangents_match_mikktspace_on_cornell():
+    s = host.Scene.load_gltf(f"{ASSETS}/cornell.gltf")
+    v, f = s.vertices.copy(), s.faces.copy()
+    # the loader derives tangents per primitive; redo it per primitive with the C library
+    starts = [0] + (np.where(np.diff(f["material"]) != 0)[0] + 1).tolist() + [len(f)]
+    ref = v.copy()
+    ref["tangent"] = 0
+    for a, b in zip(starts[:-1], starts[1:]):
+        ref = _reference_tangents(ref, f[a:b])
+    assert np.array_equal(v["tangent"].view(np.uint32), ref["tangent"].view(np.uint32))
+
+
+# ---- codecs, tonemap ---------------------------------------------------------------------------------------
+
+def test_hdr_roundtrip_and_stb_conversion(tmp_path):
+    img = np.zeros((4, 16, 3), np.float32)
+    img[..., 0] = np.linspace(0, 3, 16)
+    img[1, :, 1] = 1000.0
+    img[2, 3] = (1e-3, 2e-3, 4e-3)
+    p = scenes.write_rgbe(str(tmp_path / "t.hdr"), img)
+    got = host.load_hdr(p)
+    assert got.shape == (4, 16, 4) and (got[..., 3] == 1).all()
+    # shared exponent: the quantisation step is relative to the pixel's largest channel
+    assert (np.abs(got[..., :3] - img) <= img.max(axis=-1, keepdims=True) / 128 + 1e-9).all()
+    assert (got[0, 0, :3] == 0).all()  # exponent byte 0 -> exact zeros
+    # mantissa * 2^(e-136): every value is an integer multiple of its pixel's scale
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"#?RADIANCE")
+
+
+@needs_reference
+def test_bundled_hdr_and_png_decode():
+    hdr = host.load_hdr(f"{ASSETS}/sunny_rose_garden_1k.hdr")
+    assert hdr.shape == (512, 1024, 4) and np.isfinite(hdr).all() and hdr[..., :3].max() > 10
+    png = host.load_png(f"{ASSETS}/uv_test.png")
+    assert png.shape == (1024, 1024, 4) and png[..., 3].min() == 255
+
+
+def test_png_writer_roundtrip(tmp_path):
+    rng = np.random.RandomState(1)
+    rgb = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    lib = _ffi.host_lib()
+    path = str(tmp_path / "x.png").encode()
+    assert lib.pth_write_png_rgb8(rgb.ctypes.data, 53, 37, path) == 0
+    back = host.load_png(path.decode())
+    assert np.array_equal(back[..., :3], rgb) and (back[..., 3] == 255).all()
+
+
+def test_tonemap_reference_rules():
+    """src/image.cu:11-99: white point = max(1, max luminance), vertical flip, black -> 0 (the
+    reference's 0/0 NaN lands on 0 on x86), non-finite input refused."""
+    img = np.zeros((2, 3, 3), np.float32)
+    img[0, 0] = (1, 1, 1)
+    img[1, 2] = (0.25, 0.5, 0.75)
+    out = host.tonemap_rgb8(img)
+    assert out.shape == (2, 3, 3)
+    assert (out[1, 0] == 255).all()          # row 0 of the radiance image is the bottom row of the PNG
+    assert (out[0, 1] == 0).all()            # black pixel
+    l = np.float32(0.2126) * np.float32(0.25) + (np.float32(0.7152) * np.float32(0.5) + np.float32(0.0722) * np.float32(0.75))
+    l_new = (l * (1 + l / 1.0)) / (1 + l)
+    c = np.float32([0.25, 0.5, 0.75]) * np.float32(l_new / l)
+    want = [int(255 * (1.055 * float(x) ** (1 / 2.4) - 0.055)) for x in c]
+    assert np.abs(out[0, 2].astype(int) - np.array(want)).max() <= 1
+    bad = img.copy()
+    bad[0, 1, 1] = np.inf
+    with pytest.raises(host.HostError):
+        host.tonemap_rgb8(bad)
+
+
+# ---- oracle regression + flags + ABI surface ----------------------------------------------------------------
+
+def test_oracle_c1_golden():
+    """BASELINE config 1 through the oracle equals the committed digests (guards the oracle)."""
+    g = json.load(open(os.path.join(util.GOLDEN, "oracle_c1.json")))
+    b = util.golden_cornell()
+    o = ob.Oracle(b.scene, b.bvh, b.lst, 256, 256)
+    img, ctr = o.render_batch(42, 0, 16)
+    ids, _ = o.primary_hits(42, True)
+    assert sha(ids) == g["primary_ids_sha256"]
+    assert ctr == g["counters"]
+    assert sha(img) == g["image_sha256"]
+    assert sha(host.tonemap_rgb8(img)) == g["rgb8_sha256"]
+
+
+def test_oracle_statistics_match_survey_measurements():
+    """SURVEY.md §8a (host-compiled reference, probe RNG): cornell 7.14 rays/sample, 8.46 inner
+    visits/ray, 2.61 triangle tests/ray, 1.54 bounces/sample, 0.89 hit records/ray."""
+    b = util.golden_cornell()
+    _, c = ob.Oracle(b.scene, b.bvh, b.lst, 128, 128).render_batch(42, 0, 16)
+    assert abs(c["rays"] / c["samples"] - 7.14) < 0.05
+    assert abs(c["inner_visits"] / c["rays"] - 8.46) < 0.1
+    assert abs(c["tri_tests"] / c["rays"] - 2.61) < 0.05
+    assert abs(c["bounces"] / c["samples"] - 1.54) < 0.03
+    assert abs(c["hit_records"] / c["rays"] - 0.89) < 0.02
+
+
+def test_oracle_is_thread_count_invariant_and_rows_compose():
+    b = util.golden_cornell()
+    o = ob.Oracle(b.scene, b.bvh, b.lst, 48, 40)
+    a, _ = o.render_batch(5, 0, 3, threads=1)
+    c, _ = o.render_batch(5, 0, 3, threads=7)
+    assert np.array_equal(a, c)
+    part = np.zeros_like(a)
+    o.render_batch(5, 0, 3, part, rows=(0, 17))
+    o.render_batch(5, 0, 3, part, rows=(17, 40))
+    assert np.array_equal(part, a)
+
+
+def test_flag_surface_matches_reference():
+    """src/config.cu:63-83: same names; the last argv slot is never a flag name."""
+    lib = _ffi.host_lib()
+    argv = ["pathtracer", "--world-clear-color", "0.1 0.2 0.3", "--sampling-seed", "42", "--sampling-samples", "200",
+            "--sampling-samples-every-update", "50", "--output-resolution-x", "1024", "--output-resolution-y", "512",
+            "--output-exposure", "1.5", "--logger-log-level", "4", "--logger-log-stdout", "1", "--path-gltf", "a.gltf",
+            "--dir-output", "out", "--default-camera-position", "0 0 10", "--default-camera-target", "0 0 0",
+            "--default-camera-updir", "0 1 0", "--default-camera-yfov", "0.8"]
+    arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+    cfg = _ffi.HostConfig()
+    missing = lib.pth_load_config(C.byref(cfg), len(argv), arr)
+    assert missing == 1  # --world-clear-color-texture is "required" in the reference and absent here
+    assert (cfg.resolution_x, cfg.resolution_y, cfg.samples, cfg.seed, cfg.samples_every_update) == (1024, 512, 200, 42, 50)
+    assert abs(cfg.output_exposure - 1.5) < 1e-7 and abs(cfg.world_clear_color.y - 0.2) < 1e-7
+    assert cfg.path_gltf == b"a.gltf" and cfg.dir_output == b"out" and cfg.default_camera_yfov == np.float32(0.8)
+    # a flag in the last slot has no value and is ignored (config.cu:41)
+    arr2 = (C.c_char_p * 2)(b"pathtracer", b"--sampling-seed")
+    cfg2 = _ffi.HostConfig()
+    lib.pth_load_config(C.byref(cfg2), 2, arr2)
+    assert cfg2.seed == 0
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
+
+
+def test_shared_libraries_export_every_declared_symbol():
+    """No compute calls: only that each extern "C" name in include/*.h resolves."""
+    host_syms = _declared("pthost.h", "pth_")
+    core_syms = _declared("ptcore.h", "pt_")
+    assert len(host_syms) >= 18 and len(core_syms) >= 17
+    hl = C.CDLL(os.path.join(_ffi.LIB_DIR, "libpthost.so"))
+    for s in host_syms:
+        getattr(hl, s)
+    core_path = os.path.join(_ffi.LIB_DIR, "libptcore.so")
+    assert os.path.exists(core_path), "libptcore.so not built: run __graft_entry__.build()"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", core_path], text=True)
+    exported = set(line.split()[-1] for line in out.splitlines() if line.strip())
+    for s in core_syms:
+        assert s in exported, s
+
+
+def test_core_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pathtracer_amd import core
+    with pytest.raises(core.CoreError, match="no HIP device"):
+        core.Renderer(0)
+
+
+def test_record_layouts_match_reference_sizes():
+    """vertex_t 52, face_t 52, material_t 100, light_t 44, bvh_node_t 40, lst_node_t 8,
+    camera_t 40 bytes."""
+    assert (_ffi.VERTEX_DTYPE.itemsize, _ffi.FACE_DTYPE.itemsize, _ffi.MATERIAL_DTYPE.itemsize) == (52, 52, 100)
+    assert (_ffi.LIGHT_DTYPE.itemsize, _ffi.BVH_NODE_DTYPE.itemsize, _ffi.LST_NODE_DTYPE.itemsize) == (44, 40, 8)
+    assert C.sizeof(_ffi.Camera) == 40
+
+
+def test_texture_sampler_modes():
+    px = np.zeros((2, 2, 4), np.float32)
+    px[0, 0] = (1, 0, 0, 1)
+    px[0, 1] = (0, 1, 0, 1)
+    px[1, 0] = (0, 0, 1, 1)
+    px[1, 1] = (1, 1, 1, 1)
+    t = _ffi.Texture(2, 2, 4, 1, 0, 0, 0, 0, px.ctypes.data)  # repeat, point
+    out = np.zeros(4, np.float32)
+    L = ob.lib()
+    L.orc_sample_texture(C.byref(t), 0.25, 0.25, out.ctypes.data)
+    assert out.tolist() == [1, 0, 0, 1]
+    L.orc_sample_texture(C.byref(t), 1.75, -0.75, out.ctypes.data)  # wraps to texel (1, 0)
+    assert out.tolist() == [0, 1, 0, 1]
+    t.filter = 1
+    L.orc_sample_texture(C.byref(t), 0.5, 0.5, out.ctypes.data)  # centre: equal weights
+    assert np.allclose(out, [0.5, 0.5, 0.5, 1.0])
+    t.wrapS = t.wrapT = 2  # mirror: u and 2-u sample the same texel
+    a, b = np.zeros(4, np.float32), np.zeros(4, np.float32)
+    L.orc_sample_texture(C.byref(t), 0.3, 0.6, a.ctypes.data)
+    L.orc_sample_texture(C.byref(t), 1.7, 1.4, b.ctypes.data)
+    assert np.allclose(a, b, atol=1e-6)

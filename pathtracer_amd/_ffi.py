@@ -153,7 +153,8 @@ def core_lib():
     global _core
     if _core is not None:
         return _core
-    L = _load("libptcore.so")
+    # PT_CORE_LIB picks another build of the same ABI (kernel A/B experiments); default is the product
+    L = _load(os.environ.get("PT_CORE_LIB", "libptcore.so"))
     L.pt_last_error.restype = C.c_char_p
     L.pt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.pt_destroy.argtypes = [C.c_void_p]

@@ -251,9 +251,27 @@ PT_DEV float slab(f3 bmin, f3 bmax, f3 o, f3 rinv, float limit) {
     return (tmax >= tmin && tmin < limit && tmax > 0) ? tmin : kNoHit;
 }
 
+// The same test with v_min/v_max/v_min3/v_max3. Equal to slab() in value whenever no
+// operand is NaN (signed zeros only differ in sign, which no later compare sees); NaN needs
+// 0 * inf, i.e. an infinite reciprocal, and those rays take slab() instead.
+PT_DEV float slab_fast(f3 bmin, f3 bmax, f3 o, f3 rinv, float limit) {
+    f3 t1 = (bmin - o) * rinv;
+    f3 t2 = (bmax - o) * rinv;
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1.x, t2.x), __builtin_fminf(t1.y, t2.y)),
+                                 __builtin_fminf(t1.z, t2.z));
+    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1.x, t2.x), __builtin_fmaxf(t1.y, t2.y)),
+                                 __builtin_fmaxf(t1.z, t2.z));
+    return (tmax >= tmin && tmin < limit && tmax > 0) ? tmin : kNoHit;
+}
+
+constexpr uint32_t kDone = 0x7FFFFFFFu; // not a node index (< 2^28 triangles => < 2^28 nodes)
+
 // bvh_intersect_iterative + the triangle half of intersect_face
-// (src/bvh.cu:239-286, src/intersect.cu:12-81, :100). Same visiting order, same
-// strict "closer" test, so exact distance ties resolve to the same face.
+// (src/bvh.cu:239-286, src/intersect.cu:12-81, :100). Same visiting order per ray, same strict
+// "closer" test, so exact distance ties resolve to the same face. Shaped as a while-while
+// loop: every lane descends through inner nodes until it holds a leaf (or is done), then the
+// wave tests leaf triangles together, so node steps and triangle tests do not serialise
+// inside one wave iteration.
 template <bool COUNT, int STACK>
 PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, uint32_t *stack /* &lds[0][tid] */, Tally &n) {
     HitLite h;
@@ -261,11 +279,41 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, uint32_t *stack /* &lds[
     h.u = h.v = 0.f;
     h.face = -1;
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float inf = __builtin_inff();
+    const bool exact = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
     if (COUNT) n.walks++;
     int sp = 0;
     uint32_t ref = P.root;
-    for (;;) {
-        if (ref & kLeafBit) {
+    while (ref != kDone) {
+        while (ref < kDone) { // an inner node
+            const float4 *np = (const float4 *)(P.nodes + ref);
+            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            if (COUNT) n.inner++;
+            float t1, t2;
+            if (!exact) {
+                t1 = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, h.t);
+                t2 = slab_fast(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, h.t);
+            } else {
+                t1 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, h.t);
+                t2 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, h.t);
+            }
+            uint32_t c1 = __float_as_uint(q3.x), c2 = __float_as_uint(q3.y);
+            if (t2 < t1) {
+                uint32_t tc = c1; c1 = c2; c2 = tc;
+                float tt = t1; t1 = t2; t2 = tt;
+            }
+            if (t1 == kNoHit) {
+                ref = kDone;
+                if (sp > 0) ref = stack[(--sp) * 256];
+            } else {
+                ref = c1;
+                if (t2 != kNoHit) {
+                    if (sp < STACK) stack[sp * 256] = c2; // height is checked at upload; never overflows
+                    sp++;
+                }
+            }
+        }
+        if (ref != kDone) { // a leaf
             uint32_t first = ref & 0x0FFFFFFFu;
             uint32_t count = ((ref >> 28) & 7u) + 1;
             for (uint32_t k = 0; k < count; k++) {
@@ -291,29 +339,8 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, uint32_t *stack /* &lds[
                     h.face = (int32_t)__float_as_uint(c.y);
                 }
             }
-            if (sp == 0) break;
-            ref = stack[(--sp) * 256];
-        } else {
-            const float4 *np = (const float4 *)(P.nodes + ref);
-            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            if (COUNT) n.inner++;
-            float t1 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, h.t);
-            float t2 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, h.t);
-            uint32_t c1 = __float_as_uint(q3.x), c2 = __float_as_uint(q3.y);
-            if (t2 < t1) {
-                uint32_t tc = c1; c1 = c2; c2 = tc;
-                float tt = t1; t1 = t2; t2 = tt;
-            }
-            if (t1 == kNoHit) {
-                if (sp == 0) break;
-                ref = stack[(--sp) * 256];
-            } else {
-                ref = c1;
-                if (t2 != kNoHit) {
-                    if (sp < STACK) stack[sp * 256] = c2; // height is checked at upload; never overflows
-                    sp++;
-                }
-            }
+            ref = kDone;
+            if (sp > 0) ref = stack[(--sp) * 256];
         }
     }
     return h;

@@ -37,6 +37,11 @@ typedef struct {
     uint64_t traversals;
     uint64_t shaded_hits;
     uint64_t bounces;
+    /* Wave-level occupancy of six code regions, in order: state-machine loop, inner-node
+     * step, leaf step, main-ray handler, shadow-ray handler, BSDF sampling. iters = times a
+     * wave executed the region, lanes = sum of lanes active in it (64 * iters = full). */
+    uint64_t region_iters[6];
+    uint64_t region_lanes[6];
 } pt_counters;
 
 const char *pt_last_error(void);

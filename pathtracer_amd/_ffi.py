@@ -77,10 +77,16 @@ class Counters(C.Structure):  # orc_counters (oracle/oracle.h)
 
 class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
     _fields_ = [(n, C.c_uint64) for n in
-                ("samples", "rays", "inner_visits", "tri_tests", "traversals", "shaded_hits", "bounces")]
+                ("samples", "rays", "inner_visits", "tri_tests", "traversals", "shaded_hits", "bounces")] + \
+               [("region_iters", C.c_uint64 * 6), ("region_lanes", C.c_uint64 * 6)]
+    REGIONS = ("loop", "inner", "leaf", "main", "nee", "bsdf")
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_[:7]}
+        d["lane_utilisation"] = {r: round(self.region_lanes[i] / (64.0 * self.region_iters[i]), 4) if self.region_iters[i] else None
+                                 for i, r in enumerate(self.REGIONS)}
+        d["wave_iterations"] = {r: int(self.region_iters[i]) for i, r in enumerate(self.REGIONS)}
+        return d
 
 
 VEC3 = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")]

@@ -234,11 +234,37 @@ constexpr float kNoHit = 1e30f;
 struct HitLite {
     float t, u, v;
     int32_t face; // -1: miss
+    bool early;   // walk stopped at an occluder closer than t_stop (shadow rays only)
 };
+
+// Shadow rays need a yes/no answer, not the closest hit. A walk may start with t_init below
+// 1e30 (nothing beyond it matters) and stop at the first hit with t <= t_stop. To stay EXACTLY
+// equal to the reference's closest-hit visibility tests the two limits straddle the decisive
+// distance D by a relative band far wider than any rounding difference between the slab and
+// triangle arithmetic: t_stop = D(1-kBand) ("certainly in front"), t_init = D(1+kBand)
+// ("certainly behind"). A hit inside the band does not stop the walk, which then finishes as an
+// ordinary closest-hit walk among t < t_init, with the reference's order and tie rule, and the
+// reference's own comparison is applied to its result.
+constexpr float kBand = 1e-4f;
 
 struct Tally {
     uint32_t samples, rays, inner, tris, walks, shaded, bounces;
+    // wave-level occupancy of each code region (instrumented variant only): iterations executed by
+    // the wave, and the sum of lanes that were active in them
+    uint32_t w_iters[6], w_lanes[6];
 };
+enum : int { kRegLoop = 0, kRegInner = 1, kRegLeaf = 2, kRegMain = 3, kRegNee = 4, kRegBsdf = 5 };
+
+template <bool COUNT> PT_DEV void region_tick(Tally &n, int region) {
+    if (COUNT) {
+        unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+        unsigned lane = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (lane == 0) { // lowest active lane speaks for the wave
+            n.w_iters[region]++;
+            n.w_lanes[region] += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+}
 
 // intersect_aabb, src/bvh.cu:222-237 (select forms and tie rules kept)
 PT_DEV float slab(f3 bmin, f3 bmax, f3 o, f3 rinv, float limit) {
@@ -273,11 +299,13 @@ constexpr uint32_t kDone = 0x7FFFFFFFu; // not a node index (< 2^28 triangles =>
 // wave tests leaf triangles together, so node steps and triangle tests do not serialise
 // inside one wave iteration.
 template <bool COUNT, int STACK>
-PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, uint32_t *stack /* &lds[0][tid] */, Tally &n) {
+PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_stop, uint32_t *stack /* &lds[0][tid] */,
+                     Tally &n) {
     HitLite h;
-    h.t = kNoHit;
+    h.t = t_init;
     h.u = h.v = 0.f;
     h.face = -1;
+    h.early = false;
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float inf = __builtin_inff();
     const bool exact = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
@@ -289,6 +317,7 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, uint32_t *stack /* &lds[
             const float4 *np = (const float4 *)(P.nodes + ref);
             float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             if (COUNT) n.inner++;
+            region_tick<COUNT>(n, kRegInner);
             float t1, t2;
             if (!exact) {
                 t1 = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, h.t);
@@ -314,6 +343,7 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, uint32_t *stack /* &lds[
             }
         }
         if (ref != kDone) { // a leaf
+            region_tick<COUNT>(n, kRegLeaf);
             uint32_t first = ref & 0x0FFFFFFFu;
             uint32_t count = ((ref >> 28) & 7u) + 1;
             for (uint32_t k = 0; k < count; k++) {
@@ -337,10 +367,11 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, uint32_t *stack /* &lds[
                     h.u = u;
                     h.v = v;
                     h.face = (int32_t)__float_as_uint(c.y);
+                    if (t <= t_stop) h.early = true;
                 }
             }
             ref = kDone;
-            if (sp > 0) ref = stack[(--sp) * 256];
+            if (sp > 0 && !h.early) ref = stack[(--sp) * 256];
         }
     }
     return h;
@@ -433,9 +464,21 @@ PT_DEV void pixel_of_thread(const KernelParams &P, int *px, int *py) {
     // class gets one contiguous run of image rows.
     uint32_t nbx = ((uint32_t)P.width + 15u) / 16u, nby = ((uint32_t)P.height + 15u) / 16u;
     uint32_t nblocks = nbx * nby;
+#ifndef PT_MAP_MODE
+#define PT_MAP_MODE 2
+#endif
     uint32_t b = blockIdx.x, xcd = b % 8u, q = nblocks / 8u, r = nblocks % 8u;
     uint32_t logical = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
     uint32_t bx = logical % nbx, by = logical / nbx;
+    if (PT_MAP_MODE == 0) { bx = b % nbx; by = b / nbx; }
+    if (PT_MAP_MODE == 2) { // XCD x owns block rows x, x+8, ...: same-XCD neighbours in x, interleaved in y
+        uint32_t rows_per = (nby + 7u) / 8u;
+        uint32_t i = b / 8u;                 // index within this XCD's list
+        bx = i % nbx;
+        by = (i / nbx) * 8u + xcd;
+        (void)rows_per;
+        if (nblocks % 8u != 0 || nby % 8u != 0) { bx = b % nbx; by = b / nbx; }
+    }
     uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     *px = (int)(bx * 16u + (wave & 1u) * 8u + (lane & 7u));
     *py = (int)(by * 16u + (wave >> 1) * 8u + (lane >> 3));
@@ -449,15 +492,18 @@ PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {
     *d = normalize(a);
 }
 
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 4
+#endif
 template <bool COUNT, int STACK>
-__global__ void __launch_bounds__(256) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
+__global__ void __launch_bounds__(256, PT_MIN_WAVES) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
     __shared__ uint32_t lds_stack[STACK * 256];
     uint32_t *stack = lds_stack + threadIdx.x;
 
     int px, py;
     pixel_of_thread(P, &px, &py);
     bool inside = px < P.width && py < P.height;
-    Tally n = {0, 0, 0, 0, 0, 0, 0};
+    Tally n = {};
 
     Rng rng;
     rng_init(rng, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(py * P.width + px) : 0u);
@@ -474,6 +520,7 @@ __global__ void __launch_bounds__(256) render_kernel(KernelParams P, float *__re
     float nee_p = 0.f, nee_dist = 0.f;
     int nee_kind = 0; // 0 point, 1 directional, 2 area
     int nee_face = -1;
+    float t_init = kNoHit, t_stop = -1.0f; // limits of the next walk (see kBand)
     int mode = kModeMain;
     int sample = 0;
     bool need_camera = true;
@@ -490,15 +537,20 @@ __global__ void __launch_bounds__(256) render_kernel(KernelParams P, float *__re
             thr = mk3(1, 1, 1);
             pending = false;
             mode = kModeMain;
+            t_init = kNoHit;
+            t_stop = -1.0f;
             need_camera = false;
             if (COUNT) n.samples++;
         }
 
-        HitLite hit = trace<COUNT, STACK>(P, ro, rd, stack, n);
+        region_tick<COUNT>(n, kRegLoop);
+        HitLite hit = trace<COUNT, STACK>(P, ro, rd, t_init, t_stop, stack, n);
 
         bool do_bsdf = false;
         bool end_path = false;
+        bool skip_nee = false;
         if (mode == kModeMain) {
+            region_tick<COUNT>(n, kRegMain);
             if (COUNT) n.rays++;
             const GShade *sh = hit.face >= 0 ? P.shade + hit.face : nullptr;
             if (pending) {
@@ -614,10 +666,14 @@ __global__ void __launch_bounds__(256) render_kernel(KernelParams P, float *__re
                                     nee_kind = 0;
                                     f3 radiant_intensity = rgb_to_radiometric(lcolor, L->intensity);
                                     nee_radiance = radiant_intensity / (distance * distance);
+                                    t_init = distance + distance * kBand;
+                                    t_stop = distance - distance * kBand;
                                 } else {
                                     nee_dir = normalize(-mk3(L->direction.x, L->direction.y, L->direction.z));
                                     nee_kind = 1;
                                     nee_radiance = rgb_to_radiometric(lcolor, L->intensity);
+                                    t_init = kNoHit; // visible iff nothing at all is hit: stop at the first hit
+                                    t_stop = kNoHit;
                                 }
                             } else {
                                 const GShade *ls = P.shade + node.index;
@@ -632,24 +688,54 @@ __global__ void __launch_bounds__(256) render_kernel(KernelParams P, float *__re
                                 nee_kind = 2;
                                 nee_face = (int)node.index;
                                 nee_radiance = rgb_to_radiometric(ld3(P.materials[ls->material].emissive), 1.0f);
+                                // distance at which this ray meets the emitter itself (same arithmetic as the
+                                // walk's triangle test); without such a hit the emitter cannot be the closest face
+                                f3 so = position + 1e-6f * normal;
+                                f3 e1 = B - A, e2 = C - A;
+                                f3 pvec = cross(nee_dir, e2);
+                                float det = dot(e1, pvec);
+                                float t_f = -1.0f;
+                                if (!(det > -PT_EPS_UP && det < PT_EPS_UP)) {
+                                    float inv_det = 1.0f / det;
+                                    f3 tvec = so - A;
+                                    float u = dot(tvec, pvec) * inv_det;
+                                    if (!(u <= -PT_EPS_UP || u > 1.0f)) {
+                                        f3 qvec = cross(tvec, e1);
+                                        float v = dot(nee_dir, qvec) * inv_det;
+                                        if (!(v <= -PT_EPS_UP || (u + v) > 1.0f)) t_f = dot(e2, qvec) * inv_det;
+                                    }
+                                }
+                                if (t_f > 0) {
+                                    t_init = t_f + t_f * kBand;
+                                    t_stop = t_f - t_f * kBand;
+                                } else {
+                                    skip_nee = true;
+                                }
                             }
-                            ro = position + 1e-6f * normal;
-                            rd = nee_dir;
-                            mode = kModeNee;
+                            if (skip_nee) {
+                                if (COUNT) n.rays++; // the reference still traced this shadow ray
+                                do_bsdf = true;
+                            } else {
+                                ro = position + 1e-6f * normal;
+                                rd = nee_dir;
+                                mode = kModeNee;
+                            }
                         }
                     }
                 }
             }
         } else {
             // ---- shadow walk finished: visibility + MIS-weighted direct light ----
+            region_tick<COUNT>(n, kRegNee);
             if (COUNT) n.rays++;
             float p_lss = nee_p;
             if (nee_kind == 0) {
-                if (!(nee_dist < hit.t)) p_lss = 0;
+                float closest = hit.face >= 0 ? hit.t : kNoHit;
+                if (hit.early || !(nee_dist < closest)) p_lss = 0;
             } else if (nee_kind == 1) {
                 if (hit.face >= 0) p_lss = 0;
             } else {
-                bool visible = hit.face >= 0 && hit.t > 0 && hit.face == nee_face;
+                bool visible = !hit.early && hit.face >= 0 && hit.t > 0 && hit.face == nee_face;
                 float p_als = 0.f;
                 if (visible) p_als = area_pdf(P.shade + nee_face, nee_dir, hit.t, nullptr);
                 p_lss = visible ? p_lss * p_als : 0.f;
@@ -666,6 +752,7 @@ __global__ void __launch_bounds__(256) render_kernel(KernelParams P, float *__re
         }
 
         if (do_bsdf) {
+            region_tick<COUNT>(n, kRegBsdf);
             // BRDF::sample (brdf.cu:180-192) + next ray (renderer.cu:345-350)
             f3 r;
             do {
@@ -686,6 +773,8 @@ __global__ void __launch_bounds__(256) render_kernel(KernelParams P, float *__re
             ro = vx.position + 1e-6f * vx.normal;
             pending = true;
             mode = kModeMain;
+            t_init = kNoHit;
+            t_stop = -1.0f;
         }
 
         if (end_path) {
@@ -718,6 +807,10 @@ __global__ void __launch_bounds__(256) render_kernel(KernelParams P, float *__re
         atomicAdd(&counters[4], (unsigned long long)n.walks);
         atomicAdd(&counters[5], (unsigned long long)n.shaded);
         atomicAdd(&counters[6], (unsigned long long)n.bounces);
+        for (int k = 0; k < 6; k++) {
+            if (n.w_iters[k]) atomicAdd(&counters[8 + 2 * k], (unsigned long long)n.w_iters[k]);
+            if (n.w_lanes[k]) atomicAdd(&counters[9 + 2 * k], (unsigned long long)n.w_lanes[k]);
+        }
     }
 }
 
@@ -739,8 +832,8 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(KernelParams P, int32
     float v = (2 * sy - (float)P.height) / (float)P.height;
     f3 o, d;
     camera_ray(P, u, v, &o, &d);
-    Tally n = {0, 0, 0, 0, 0, 0, 0};
-    HitLite h = trace<false, STACK>(P, o, d, stack, n);
+    Tally n = {};
+    HitLite h = trace<false, STACK>(P, o, d, kNoHit, -1.0f, stack, n);
     size_t at = (size_t)py * (size_t)P.width + (size_t)px;
     faces[at] = h.face;
     if (dist) dist[at] = h.t;

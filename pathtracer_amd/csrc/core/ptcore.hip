@@ -198,8 +198,8 @@ extern "C" int pt_create(int device, pt_context **out) {
     HIP_TRY(hipEventCreate(&ctx->ev_stop));
     std::vector<uint32_t> tables = build_jump_tables();
     if (ctx->jump.upload(tables.data(), tables.size())) return 1;
-    unsigned long long zeros[8] = {0};
-    if (ctx->counters.upload(zeros, 8)) return 1;
+    unsigned long long zeros[20] = {0};
+    if (ctx->counters.upload(zeros, 20)) return 1;
     ctx->P.jump = ctx->jump.ptr;
     *out = ctx;
     return 0;
@@ -486,8 +486,12 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
     launch_render<true>(ctx, nullptr, ctx->counters.ptr, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long h[8];
+    unsigned long long h[20];
     HIP_TRY(hipMemcpy(h, ctx->counters.ptr, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 6; k++) {
+        out->region_iters[k] = h[8 + 2 * k];
+        out->region_lanes[k] = h[9 + 2 * k];
+    }
     out->samples = h[0];
     out->rays = h[1];
     out->inner_visits = h[2];

@@ -42,6 +42,11 @@ typedef struct {
      * wave executed the region, lanes = sum of lanes active in it (64 * iters = full). */
     uint64_t region_iters[6];
     uint64_t region_lanes[6];
+    /* Shader-clock ticks summed over waves: [0] inside the walk slices, [1] node phases,
+     * [2] leaf phases, [3] result handling + shading + next-ray set-up, [4],[5] unused;
+     * wave_ticks = sum of wave lifetimes (includes RNG init and the image write). */
+    uint64_t region_ticks[6];
+    uint64_t wave_ticks;
 } pt_counters;
 
 const char *pt_last_error(void);

@@ -78,7 +78,8 @@ class Counters(C.Structure):  # orc_counters (oracle/oracle.h)
 class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
     _fields_ = [(n, C.c_uint64) for n in
                 ("samples", "rays", "inner_visits", "tri_tests", "traversals", "shaded_hits", "bounces")] + \
-               [("region_iters", C.c_uint64 * 6), ("region_lanes", C.c_uint64 * 6)]
+               [("region_iters", C.c_uint64 * 6), ("region_lanes", C.c_uint64 * 6),
+                ("region_ticks", C.c_uint64 * 6), ("wave_ticks", C.c_uint64)]
     REGIONS = ("loop", "inner", "leaf", "main", "nee", "bsdf")
 
     def as_dict(self):
@@ -86,6 +87,9 @@ class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
         d["lane_utilisation"] = {r: round(self.region_lanes[i] / (64.0 * self.region_iters[i]), 4) if self.region_iters[i] else None
                                  for i, r in enumerate(self.REGIONS)}
         d["wave_iterations"] = {r: int(self.region_iters[i]) for i, r in enumerate(self.REGIONS)}
+        if self.wave_ticks:
+            names = ("walk_slices", "node_phases", "leaf_phases", "shading")
+            d["time_share"] = {nm: round(self.region_ticks[i] / self.wave_ticks, 4) for i, nm in enumerate(names)}
         return d
 
 

@@ -38,6 +38,12 @@ namespace ptc {
 
 #define PT_DEV __device__ __forceinline__
 
+#ifndef PT_BLOCK
+#define PT_BLOCK 64 /* threads per workgroup: one wave64 = one 8x8 pixel tile */
+#endif
+constexpr int kBlock = PT_BLOCK;
+
+
 struct f3 {
     float x, y, z;
 };
@@ -252,8 +258,21 @@ struct Tally {
     // wave-level occupancy of each code region (instrumented variant only): iterations executed by
     // the wave, and the sum of lanes that were active in them
     uint32_t w_iters[6], w_lanes[6];
+    unsigned long long *w_time; // LDS: shader-clock ticks per region, written by the wave's leader lane
 };
 enum : int { kRegLoop = 0, kRegInner = 1, kRegLeaf = 2, kRegMain = 3, kRegNee = 4, kRegBsdf = 5 };
+
+template <bool COUNT> PT_DEV unsigned long long stamp() {
+    if (COUNT) return __builtin_amdgcn_s_memtime();
+    return 0;
+}
+template <bool COUNT> PT_DEV void region_time(Tally &n, int region, unsigned long long t0, unsigned long long t1) {
+    if (COUNT) {
+        unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+        unsigned lane = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (lane == 0) n.w_time[region] += t1 - t0;
+    }
+}
 
 template <bool COUNT> PT_DEV void region_tick(Tally &n, int region) {
     if (COUNT) {
@@ -333,11 +352,11 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
             }
             if (t1 == kNoHit) {
                 ref = kDone;
-                if (sp > 0) ref = stack[(--sp) * 256];
+                if (sp > 0) ref = stack[(--sp) * kBlock];
             } else {
                 ref = c1;
                 if (t2 != kNoHit) {
-                    if (sp < STACK) stack[sp * 256] = c2; // height is checked at upload; never overflows
+                    if (sp < STACK) stack[sp * kBlock] = c2; // height is checked at upload; never overflows
                     sp++;
                 }
             }
@@ -371,10 +390,163 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
                 }
             }
             ref = kDone;
-            if (sp > 0 && !h.early) ref = stack[(--sp) * 256];
+            if (sp > 0 && !h.early) ref = stack[(--sp) * kBlock];
         }
     }
     return h;
+}
+
+// ---- sliced, speculative walk ------------------------------------------------------------
+//
+// The same closest-hit walk, restructured for a 64-wide wave:
+//  * Speculation: a lane that reaches a leaf parks it (`pleaf`) and keeps descending; leaf
+//    triangles are tested later, in the order the leaves were found. The lane therefore
+//    culls with a slightly stale (larger) best distance and may visit nodes the reference
+//    would have skipped; every face the reference tests is still tested, in the same relative
+//    order, with the same strict "closer" rule, so the result is the same.
+//  * Wave-uniform phases: the node loop runs while no lane is blocked (holding a parked leaf
+//    AND standing on another one), so no lane idles while others descend; then one leaf phase
+//    serves every parked leaf.
+//  * Time slicing: a slice ends after PT_SLICE node iterations. Lanes whose walk finished go
+//    on to shading and come back with a new ray; lanes still walking keep (ref, sp, pleaf, h)
+//    and resume in the next slice. One very long walk no longer holds 63 lanes hostage.
+#ifndef PT_SLICE
+#define PT_SLICE 16
+#endif
+#ifndef PT_BLOCKED_SHIFT
+#define PT_BLOCKED_SHIFT 1 /* leave the node loop when blocked lanes >= stepping lanes >> shift */
+#endif
+
+struct Walk {
+    uint32_t ref;   // next node/leaf reference, kDone when the walk is finished
+    uint32_t pleaf; // parked leaf reference, 0 = none
+    int sp;
+    HitLite h;
+};
+
+// Moeller-Trumbore on one pre-gathered triangle (src/intersect.cu:12-81, non-culling branch)
+// followed by the "closer" test of intersect_face (src/intersect.cu:100).
+PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop, HitLite &h) {
+    f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+    f3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    if (det > -PT_EPS_UP && det < PT_EPS_UP) return;
+    float inv_det = 1.0f / det;
+    f3 tvec = o - v0;
+    float u = dot(tvec, pvec) * inv_det;
+    if (u <= -PT_EPS_UP || u > 1.0f) return;
+    f3 qvec = cross(tvec, e1);
+    float v = dot(d, qvec) * inv_det;
+    if (v <= -PT_EPS_UP || (u + v) > 1.0f) return;
+    float t = dot(e2, qvec) * inv_det;
+    if (t >= 0 && t < h.t) {
+        h.t = t;
+        h.u = u;
+        h.v = v;
+        h.face = (int32_t)__float_as_uint(c.y);
+        if (t <= t_stop) h.early = true;
+    }
+}
+
+// Leaves of the reference builder hold one or two faces (src/bvh.cu:143): both records are
+// fetched before either is tested so the second fetch does not wait for the first test.
+template <bool COUNT>
+PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_stop, HitLite &h, Tally &n) {
+    uint32_t first = leaf & 0x0FFFFFFFu;
+    uint32_t count = ((leaf >> 28) & 7u) + 1;
+    const float4 *tp = (const float4 *)(P.tris + first);
+    uint32_t second = count > 1 ? 3u : 0u; // re-reads triangle 0 when the leaf has one face (result unused)
+    float4 a0 = tp[0], b0 = tp[1], c0 = tp[2];
+    float4 a1 = tp[second + 0], b1 = tp[second + 1], c1 = tp[second + 2];
+    if (COUNT) n.tris += count;
+    test_triangle(a0, b0, c0, o, d, t_stop, h);
+    if (count > 1) test_triangle(a1, b1, c1, o, d, t_stop, h);
+    for (uint32_t k = 2; k < count; k++) {
+        const float4 *tq = (const float4 *)(P.tris + first + k);
+        test_triangle(tq[0], tq[1], tq[2], o, d, t_stop, h);
+    }
+}
+
+template <bool COUNT, int STACK>
+PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t *stack, Walk &w, Tally &n) {
+    f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float inf = __builtin_inff();
+    const bool exact = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
+    int steps = 0; // wave-uniform: every exit test below is a ballot or this counter
+    for (;;) {
+        unsigned long long ts0 = stamp<COUNT>();
+        for (;;) {
+            bool stepping = w.ref < kDone;
+            bool blocked = w.ref > kDone && w.pleaf != 0;
+            unsigned long long m_step = __builtin_amdgcn_ballot_w64(stepping);
+            unsigned long long m_blocked = __builtin_amdgcn_ballot_w64(blocked);
+            int n_step = __builtin_popcountll(m_step), n_blocked = __builtin_popcountll(m_blocked);
+            if (n_step == 0 || steps >= PT_SLICE || (n_blocked != 0 && n_blocked >= (n_step >> PT_BLOCKED_SHIFT))) break;
+            steps++;
+            if (stepping) {
+                const float4 *np = (const float4 *)(P.nodes + w.ref);
+                float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                if (COUNT) n.inner++;
+                region_tick<COUNT>(n, kRegInner);
+                float t1, t2;
+                if (!exact) {
+                    t1 = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, w.h.t);
+                    t2 = slab_fast(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, w.h.t);
+                } else {
+                    t1 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, w.h.t);
+                    t2 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, w.h.t);
+                }
+                uint32_t c1 = __float_as_uint(q3.x), c2 = __float_as_uint(q3.y);
+                if (t2 < t1) {
+                    uint32_t tc = c1; c1 = c2; c2 = tc;
+                    float tt = t1; t1 = t2; t2 = tt;
+                }
+                uint32_t next;
+                if (t1 == kNoHit) {
+                    next = kDone;
+                    if (w.sp > 0) next = stack[(--w.sp) * kBlock];
+                } else {
+                    next = c1;
+                    if (t2 != kNoHit) {
+                        if (w.sp < STACK) stack[w.sp * kBlock] = c2; // height is checked at upload; never overflows
+                        w.sp++;
+                    }
+                }
+                if (next > kDone && w.pleaf == 0) { // a leaf and room to park it: keep descending
+                    w.pleaf = next;
+                    next = kDone;
+                    if (w.sp > 0) next = stack[(--w.sp) * kBlock];
+                }
+                w.ref = next;
+            }
+        }
+        unsigned long long ts1 = stamp<COUNT>();
+        region_time<COUNT>(n, kRegInner, ts0, ts1);
+        // leaf phase: parked leaves first, then the leaf a lane stands on (order of discovery)
+        bool any_leaf = false;
+        for (;;) {
+            bool has = w.pleaf != 0;
+            if (__builtin_amdgcn_ballot_w64(has) == 0) break;
+            any_leaf = true;
+            if (has) {
+                region_tick<COUNT>(n, kRegLeaf);
+                test_leaf<COUNT>(P, w.pleaf, o, d, t_stop, w.h, n);
+                w.pleaf = 0;
+                if (w.h.early) {
+                    w.ref = kDone;
+                    w.sp = 0;
+                } else if (w.ref > kDone) { // standing on the next leaf: park it, step off
+                    w.pleaf = w.ref;
+                    w.ref = kDone;
+                    if (w.sp > 0) w.ref = stack[(--w.sp) * kBlock];
+                }
+            }
+        }
+        region_time<COUNT>(n, kRegLeaf, ts1, stamp<COUNT>());
+        bool more = w.ref < kDone;
+        if (steps >= PT_SLICE || __builtin_amdgcn_ballot_w64(more) == 0) break;
+        (void)any_leaf;
+    }
 }
 
 // ---- BRDF (src/brdf.cu:3-56, 164-178) ------------------------------------------------------
@@ -390,7 +562,12 @@ PT_DEV float g1_schlick_ggx(float n_dot_v, float roughness) {
     return n_dot_v / (n_dot_v * (1.0f - k) + k);
 }
 
-__device__ __noinline__ f3 brdf_eval(Brdf b, f3 wo, f3 wi) {
+#ifdef PT_INLINE_BRDF
+PT_DEV
+#else
+__device__ __noinline__
+#endif
+f3 brdf_eval(Brdf b, f3 wo, f3 wi) {
     float cos_theta_wi = max_gl(wi.z, 0.0f);
     f3 l = wi, v = wo;
     f3 h = normalize(l + v);
@@ -458,30 +635,21 @@ PT_DEV float area_pdf(const GShade *s, f3 dir, float t, f3 *normal_out) {
 }
 
 PT_DEV void pixel_of_thread(const KernelParams &P, int *px, int *py) {
-    // 256 threads = a 16x16 pixel block (the reference's block shape,
-    // src/main.cu:85); each wave owns an 8x8 quadrant so its 64 rays stay close.
-    // Blocks sharing blockIdx % 8 share an XCD and its L2, so each residue
-    // class gets one contiguous run of image rows.
-    uint32_t nbx = ((uint32_t)P.width + 15u) / 16u, nby = ((uint32_t)P.height + 15u) / 16u;
-    uint32_t nblocks = nbx * nby;
-#ifndef PT_MAP_MODE
-#define PT_MAP_MODE 2
-#endif
-    uint32_t b = blockIdx.x, xcd = b % 8u, q = nblocks / 8u, r = nblocks % 8u;
-    uint32_t logical = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
-    uint32_t bx = logical % nbx, by = logical / nbx;
-    if (PT_MAP_MODE == 0) { bx = b % nbx; by = b / nbx; }
-    if (PT_MAP_MODE == 2) { // XCD x owns block rows x, x+8, ...: same-XCD neighbours in x, interleaved in y
-        uint32_t rows_per = (nby + 7u) / 8u;
-        uint32_t i = b / 8u;                 // index within this XCD's list
-        bx = i % nbx;
-        by = (i / nbx) * 8u + xcd;
-        (void)rows_per;
-        if (nblocks % 8u != 0 || nby % 8u != 0) { bx = b % nbx; by = b / nbx; }
+    // One wave64 renders one 8x8 pixel tile, so its 64 primary rays stay close. With
+    // one-wave workgroups the dispatcher balances at tile granularity (a 16x16 block of four
+    // waves left 38 % of the wave slots empty in the tail of a launch). Workgroups that share
+    // blockIdx % 8 share an XCD and its L2: XCD x takes tile rows x, x+8, ..., so every XCD
+    // sees the whole picture (balance) while horizontal neighbours stay on one L2.
+    uint32_t ntx = ((uint32_t)P.width + 7u) / 8u, nty = ((uint32_t)P.height + 7u) / 8u;
+    uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    uint32_t tx = wave % ntx, ty = wave / ntx;
+    if (nty % 8u == 0) {
+        uint32_t xcd = wave % 8u, i = wave / 8u;
+        tx = i % ntx;
+        ty = (i / ntx) * 8u + xcd;
     }
-    uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    *px = (int)(bx * 16u + (wave & 1u) * 8u + (lane & 7u));
-    *py = (int)(by * 16u + (wave >> 1) * 8u + (lane >> 3));
+    *px = (int)(tx * 8u + (lane & 7u));
+    *py = (int)(ty * 8u + (lane >> 3));
 }
 
 PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {
@@ -493,17 +661,23 @@ PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {
 }
 
 #ifndef PT_MIN_WAVES
-#define PT_MIN_WAVES 4
+#define PT_MIN_WAVES 3
 #endif
 template <bool COUNT, int STACK>
-__global__ void __launch_bounds__(256, PT_MIN_WAVES) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
-    __shared__ uint32_t lds_stack[STACK * 256];
+__global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
+    __shared__ uint32_t lds_stack[STACK * kBlock];
+    __shared__ unsigned long long lds_time[COUNT ? 8 * (kBlock / 64) : 1];
     uint32_t *stack = lds_stack + threadIdx.x;
 
     int px, py;
     pixel_of_thread(P, &px, &py);
     bool inside = px < P.width && py < P.height;
     Tally n = {};
+    if (COUNT) {
+        n.w_time = lds_time + 8 * (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) < 8) n.w_time[threadIdx.x & 63] = 0;
+    }
+    unsigned long long t_kernel0 = stamp<COUNT>();
 
     Rng rng;
     rng_init(rng, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(py * P.width + px) : 0u);
@@ -521,6 +695,8 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) render_kernel(KernelParams 
     int nee_kind = 0; // 0 point, 1 directional, 2 area
     int nee_face = -1;
     float t_init = kNoHit, t_stop = -1.0f; // limits of the next walk (see kBand)
+    Walk wk = {};
+    bool walking = false;
     int mode = kModeMain;
     int sample = 0;
     bool need_camera = true;
@@ -544,7 +720,33 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) render_kernel(KernelParams 
         }
 
         region_tick<COUNT>(n, kRegLoop);
+        unsigned long long tl0 = stamp<COUNT>();
+#if PT_SLICE > 0
+        if (!walking) { // start the walk of the ray set up by the previous iteration
+            wk.ref = P.root;
+            wk.pleaf = 0;
+            wk.sp = 0;
+            wk.h.t = t_init;
+            wk.h.u = wk.h.v = 0.f;
+            wk.h.face = -1;
+            wk.h.early = false;
+            if (wk.ref > kDone) { // the whole tree is one leaf
+                wk.pleaf = wk.ref;
+                wk.ref = kDone;
+            }
+            if (COUNT) n.walks++;
+            walking = true;
+        }
+        walk_slice<COUNT, STACK>(P, ro, rd, t_stop, stack, wk, n);
+        region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
+        if (wk.ref != kDone || wk.pleaf != 0) continue; // still walking: next slice
+        walking = false;
+        unsigned long long tsh0 = stamp<COUNT>();
+        HitLite hit = wk.h;
+        if (hit.face < 0) hit.t = kNoHit;
+#else
         HitLite hit = trace<COUNT, STACK>(P, ro, rd, t_init, t_stop, stack, n);
+#endif
 
         bool do_bsdf = false;
         bool end_path = false;
@@ -777,6 +979,9 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) render_kernel(KernelParams 
             t_stop = -1.0f;
         }
 
+#if PT_SLICE > 0
+        region_time<COUNT>(n, kRegMain, tsh0, stamp<COUNT>());
+#endif
         if (end_path) {
             total = total + light;
             sample++;
@@ -811,13 +1016,17 @@ __global__ void __launch_bounds__(256, PT_MIN_WAVES) render_kernel(KernelParams 
             if (n.w_iters[k]) atomicAdd(&counters[8 + 2 * k], (unsigned long long)n.w_iters[k]);
             if (n.w_lanes[k]) atomicAdd(&counters[9 + 2 * k], (unsigned long long)n.w_lanes[k]);
         }
+        if ((threadIdx.x & 63) == 0) { // lane 0 always reaches the end of the kernel
+            for (int k = 0; k < 6; k++) atomicAdd(&counters[20 + k], n.w_time[k]);
+            atomicAdd(&counters[26], stamp<COUNT>() - t_kernel0); // wave lifetime
+        }
     }
 }
 
 // First camera ray of every pixel: face id + distance (parity probe).
 template <int STACK>
-__global__ void __launch_bounds__(256) primary_hits_kernel(KernelParams P, int32_t *__restrict__ faces, float *__restrict__ dist) {
-    __shared__ uint32_t lds_stack[STACK * 256];
+__global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, int32_t *__restrict__ faces, float *__restrict__ dist) {
+    __shared__ uint32_t lds_stack[STACK * kBlock];
     uint32_t *stack = lds_stack + threadIdx.x;
     int px, py;
     pixel_of_thread(P, &px, &py);

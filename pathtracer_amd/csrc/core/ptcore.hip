@@ -167,12 +167,13 @@ void set_launch(pt_context *ctx, int seed, int prev, int cur, int jitter) {
 }
 
 dim3 grid_of(const pt_context *ctx) {
-    uint32_t nbx = ((uint32_t)ctx->P.width + 15u) / 16u, nby = ((uint32_t)ctx->P.height + 15u) / 16u;
-    return dim3(nbx * nby);
+    uint32_t ntx = ((uint32_t)ctx->P.width + 7u) / 8u, nty = ((uint32_t)ctx->P.height + 7u) / 8u;
+    uint32_t waves = ntx * nty, per_block = kBlock / 64;
+    return dim3((waves + per_block - 1) / per_block);
 }
 
 template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned long long *counters, hipStream_t st) {
-    dim3 grid = grid_of(ctx), block(256);
+    dim3 grid = grid_of(ctx), block(kBlock);
     if (ctx->bvh_height <= 33)
         hipLaunchKernelGGL((render_kernel<COUNT, 32>), grid, block, 0, st, ctx->P, img, counters);
     else
@@ -198,8 +199,8 @@ extern "C" int pt_create(int device, pt_context **out) {
     HIP_TRY(hipEventCreate(&ctx->ev_stop));
     std::vector<uint32_t> tables = build_jump_tables();
     if (ctx->jump.upload(tables.data(), tables.size())) return 1;
-    unsigned long long zeros[20] = {0};
-    if (ctx->counters.upload(zeros, 20)) return 1;
+    unsigned long long zeros[32] = {0};
+    if (ctx->counters.upload(zeros, 32)) return 1;
     ctx->P.jump = ctx->jump.ptr;
     *out = ctx;
     return 0;
@@ -466,9 +467,9 @@ extern "C" int pt_primary_hits(pt_context *ctx, int seed, int jitter, int32_t *h
     }
     set_launch(ctx, seed, 0, 1, jitter);
     if (ctx->bvh_height <= 33)
-        hipLaunchKernelGGL((primary_hits_kernel<32>), grid_of(ctx), dim3(256), 0, ctx->stream, ctx->P, d_faces, d_dist);
+        hipLaunchKernelGGL((primary_hits_kernel<32>), grid_of(ctx), dim3(kBlock), 0, ctx->stream, ctx->P, d_faces, d_dist);
     else
-        hipLaunchKernelGGL((primary_hits_kernel<64>), grid_of(ctx), dim3(256), 0, ctx->stream, ctx->P, d_faces, d_dist);
+        hipLaunchKernelGGL((primary_hits_kernel<64>), grid_of(ctx), dim3(kBlock), 0, ctx->stream, ctx->P, d_faces, d_dist);
     e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(host_face_ids, d_faces, n * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess && host_distances) e = hipMemcpy(host_distances, d_dist, n * sizeof(float), hipMemcpyDeviceToHost);
@@ -486,12 +487,14 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
     launch_render<true>(ctx, nullptr, ctx->counters.ptr, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long h[20];
+    unsigned long long h[32];
     HIP_TRY(hipMemcpy(h, ctx->counters.ptr, sizeof(h), hipMemcpyDeviceToHost));
     for (int k = 0; k < 6; k++) {
         out->region_iters[k] = h[8 + 2 * k];
         out->region_lanes[k] = h[9 + 2 * k];
+        out->region_ticks[k] = h[20 + k];
     }
+    out->wave_ticks = h[26];
     out->samples = h[0];
     out->rays = h[1];
     out->inner_visits = h[2];

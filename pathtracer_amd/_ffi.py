@@ -90,6 +90,7 @@ class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
         if self.wave_ticks:
             names = ("walk_slices", "node_phases", "leaf_phases", "shading")
             d["time_share"] = {nm: round(self.region_ticks[i] / self.wave_ticks, 4) for i, nm in enumerate(names)}
+            d["wave_ticks"] = int(self.wave_ticks)
         return d
 
 

@@ -83,10 +83,12 @@ struct KernelParams {
     const GMaterial *materials;
     const pt_light *lights;
     const pt_lst_node *lst;
+    const GLight *glights; // one baked record per LST node
     const Texture *textures;
     const uint32_t *jump; // [32][160][8] words: XORWOW A^(2^67 * 2^k), rows padded to 8
     uint32_t root;
     uint32_t lst_count;
+    uint32_t lst_face_nodes; // LST nodes that are emissive faces (one light-pdf ray each in the reference)
     int32_t clear_texture;
     // image
     int32_t width, height;
@@ -240,6 +242,7 @@ constexpr float kNoHit = 1e30f;
 struct HitLite {
     float t, u, v;
     int32_t face; // -1: miss
+    uint32_t material;
     bool early;   // walk stopped at an occluder closer than t_stop (shadow rays only)
 };
 
@@ -324,6 +327,7 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
     h.t = t_init;
     h.u = h.v = 0.f;
     h.face = -1;
+    h.material = 0;
     h.early = false;
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float inf = __builtin_inff();
@@ -386,6 +390,7 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
                     h.u = u;
                     h.v = v;
                     h.face = (int32_t)__float_as_uint(c.y);
+                    h.material = __float_as_uint(c.z);
                     if (t <= t_stop) h.early = true;
                 }
             }
@@ -444,6 +449,7 @@ PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop
         h.u = u;
         h.v = v;
         h.face = (int32_t)__float_as_uint(c.y);
+        h.material = __float_as_uint(c.z);
         if (t <= t_stop) h.early = true;
     }
 }
@@ -693,7 +699,7 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
     f3 nee_dir = mk3(0, 0, 0), nee_radiance = mk3(0, 0, 0);
     float nee_p = 0.f, nee_dist = 0.f;
     int nee_kind = 0; // 0 point, 1 directional, 2 area
-    int nee_face = -1;
+    uint32_t nee_light = 0;
     float t_init = kNoHit, t_stop = -1.0f; // limits of the next walk (see kBand)
     Walk wk = {};
     bool walking = false;
@@ -729,6 +735,7 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
             wk.h.t = t_init;
             wk.h.u = wk.h.v = 0.f;
             wk.h.face = -1;
+            wk.h.material = 0;
             wk.h.early = false;
             if (wk.ref > kDone) { // the whole tree is one leaf
                 wk.pleaf = wk.ref;
@@ -754,15 +761,21 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
         if (mode == kModeMain) {
             region_tick<COUNT>(n, kRegMain);
             if (COUNT) n.rays++;
-            const GShade *sh = hit.face >= 0 ? P.shade + hit.face : nullptr;
+            const bool sh = hit.face >= 0;
+            GShade s;
+            GMaterial m;
+            if (sh) { // both records are addressed by the walk's result, so the two fetches overlap
+                s = P.shade[hit.face];
+                m = P.materials[hit.material];
+            }
             if (pending) {
                 // evaluate_direct_p: only the LST node whose face this ray hit contributes
                 float p_direct = 0.f;
                 if (P.lst_count != 0) {
-                    if (sh && (sh->flags & kShadeIsLight) && hit.t > 0) {
+                    if (sh && (s.flags & kShadeIsLight) && hit.t > 0) {
                         // a face listed k times in the LST contributes k equal terms
-                        float p_als = area_pdf(sh, rd, hit.t, nullptr);
-                        for (uint32_t k = sh->flags >> 8; k > 0; k--) p_direct += p_als;
+                        float p_als = area_pdf(&s, rd, hit.t, nullptr);
+                        for (uint32_t k = s.flags >> 8; k > 0; k--) p_direct += p_als;
                     }
                     p_direct = p_direct / (float)P.lst_count;
                 }
@@ -785,8 +798,6 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
                 end_path = true;
             } else {
                 // ---- hit record (intersect.cu:100-198) ----
-                GShade s = *sh;
-                GMaterial m = P.materials[s.material];
                 float u = hit.u, v = hit.v;
                 float w = (float)(1.0 - (double)u - (double)v);
                 f3 position = (w * ld3(s.pos[0]) + u * ld3(s.pos[1])) + v * ld3(s.pos[2]);
@@ -855,31 +866,25 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
                             do_bsdf = true;
                         } else {
                             int node_index = (int)((float)P.lst_count * rng_uniform(rng));
-                            pt_lst_node node = P.lst[(uint32_t)node_index % P.lst_count];
+                            nee_light = (uint32_t)node_index % P.lst_count;
+                            GLight gl = P.glights[nee_light];
                             nee_p = 1.0f / (float)P.lst_count;
-                            if (node.type == PT_LST_SOURCE_LIGHT) {
-                                const pt_light *L = P.lights + node.index;
-                                f3 lcolor = mk3(L->color.x, L->color.y, L->color.z);
-                                if (L->type == PT_LIGHT_POINT) {
-                                    f3 dl = mk3(L->position.x, L->position.y, L->position.z) - position;
-                                    float distance = length(dl);
-                                    nee_dir = dl / distance;
-                                    nee_dist = distance;
-                                    nee_kind = 0;
-                                    f3 radiant_intensity = rgb_to_radiometric(lcolor, L->intensity);
-                                    nee_radiance = radiant_intensity / (distance * distance);
-                                    t_init = distance + distance * kBand;
-                                    t_stop = distance - distance * kBand;
-                                } else {
-                                    nee_dir = normalize(-mk3(L->direction.x, L->direction.y, L->direction.z));
-                                    nee_kind = 1;
-                                    nee_radiance = rgb_to_radiometric(lcolor, L->intensity);
-                                    t_init = kNoHit; // visible iff nothing at all is hit: stop at the first hit
-                                    t_stop = kNoHit;
-                                }
+                            nee_kind = (int)gl.kind;
+                            nee_radiance = ld3(gl.radiance);
+                            f3 A = ld3(gl.a), B = ld3(gl.b), C = ld3(gl.c);
+                            if (gl.kind == 0) {
+                                f3 dl = A - position;
+                                float distance = length(dl);
+                                nee_dir = dl / distance;
+                                nee_dist = distance;
+                                nee_radiance = nee_radiance / (distance * distance);
+                                t_init = distance + distance * kBand;
+                                t_stop = distance - distance * kBand;
+                            } else if (gl.kind == 1) {
+                                nee_dir = A;
+                                t_init = kNoHit; // visible iff nothing at all is hit: stop at the first hit
+                                t_stop = kNoHit;
                             } else {
-                                const GShade *ls = P.shade + node.index;
-                                f3 A = ld3(ls->pos[0]), B = ld3(ls->pos[1]), C = ld3(ls->pos[2]);
                                 float u1, u2;
                                 do {
                                     u1 = rng_uniform(rng);
@@ -887,9 +892,6 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
                                 } while (u1 + u2 > 1);
                                 f3 light_pos = (A + u1 * (B - A)) + u2 * (C - A);
                                 nee_dir = normalize(light_pos - position);
-                                nee_kind = 2;
-                                nee_face = (int)node.index;
-                                nee_radiance = rgb_to_radiometric(ld3(P.materials[ls->material].emissive), 1.0f);
                                 // distance at which this ray meets the emitter itself (same arithmetic as the
                                 // walk's triangle test); without such a hit the emitter cannot be the closest face
                                 f3 so = position + 1e-6f * normal;
@@ -937,9 +939,13 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
             } else if (nee_kind == 1) {
                 if (hit.face >= 0) p_lss = 0;
             } else {
-                bool visible = !hit.early && hit.face >= 0 && hit.t > 0 && hit.face == nee_face;
+                const GLight *gl = P.glights + nee_light;
+                bool visible = !hit.early && hit.face >= 0 && hit.t > 0 && hit.face == (int32_t)gl->face;
                 float p_als = 0.f;
-                if (visible) p_als = area_pdf(P.shade + nee_face, nee_dir, hit.t, nullptr);
+                if (visible) { // sample_area_light, renderer.cu:131-133, with the emitter's baked normal and area
+                    float cos_theta_y = __builtin_fabsf(dot(ld3(gl->normal), nee_dir));
+                    p_als = hit.t * hit.t / (gl->area * cos_theta_y);
+                }
                 p_lss = visible ? p_lss * p_als : 0.f;
             }
             if (p_lss > 0) {
@@ -968,8 +974,7 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
             if (COUNT) {
                 n.bounces++;
                 // the reference walks the BVH once per emissive LST node for the pdf
-                for (uint32_t i = 0; i < P.lst_count; i++)
-                    if (P.lst[i].type == PT_LST_SOURCE_FACE) n.rays++;
+                n.rays += P.lst_face_nodes;
             }
             rd = tbn_mul(vx, wi);
             ro = vx.position + 1e-6f * vx.normal;

@@ -43,7 +43,8 @@ static_assert(sizeof(GNode) == 64, "GNode must be one 64-byte line");
 struct alignas(16) GTri {
     float v0[3], e1[3], e2[3];
     uint32_t face;
-    uint32_t pad[2];
+    uint32_t material; // copy of the face's material index: lets the material fetch start with the hit
+    uint32_t pad;
 };
 static_assert(sizeof(GTri) == 48, "GTri is three 16-byte loads");
 
@@ -70,6 +71,23 @@ struct alignas(16) GMaterial {
     uint32_t pad;
 };
 static_assert(sizeof(GMaterial) == 64, "GMaterial is four 16-byte loads");
+
+// One record per LST node, everything sample_light_source needs in one 80-byte fetch
+// (the reference chases lst node -> light | face -> 3 vertices -> material). The radiometric
+// conversion (renderer.cu:146-162), the sun direction and the emitter's normal and area
+// (renderer.cu:102-105) depend only on the scene, so the host computes them once with the
+// reference's operation order.
+struct alignas(16) GLight {
+    uint32_t kind;      // 0 point, 1 directional, 2 emissive face
+    uint32_t face;      // kind 2: face index
+    float a[3];         // point: position; directional: normalize(-direction); face: vertex A
+    float b[3], c[3];   // face: vertices B, C
+    float radiance[3];  // rgb_to_radiometric(color, intensity) | (emissive, 1)
+    float normal[3];    // face: tri_cross / |tri_cross|
+    float area;         // face: 0.5 * |tri_cross|
+    float pad[2];
+};
+static_assert(sizeof(GLight) == 80, "GLight is five 16-byte loads");
 
 struct GTexture {
     const void *texels; // device pointer, RGBA float or RGBA8
@@ -113,6 +131,7 @@ inline std::string bake_bvh(const std::vector<GShade> &shade, const pt_bvh_node 
         t.e1[0] = b[0] - a[0]; t.e1[1] = b[1] - a[1]; t.e1[2] = b[2] - a[2];
         t.e2[0] = c[0] - a[0]; t.e2[1] = c[1] - a[1]; t.e2[2] = c[2] - a[2];
         t.face = f;
+        t.material = shade[f].material;
         out.tris.push_back(t);
     }
 

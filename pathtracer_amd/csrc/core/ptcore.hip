@@ -108,6 +108,17 @@ H3 hcross(H3 a, H3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.
 float hdot(H3 a, H3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
 H3 hscale(H3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 H3 hunit(H3 a) { return hscale(a, (float)(1.0 / (double)sqrtf(hdot(a, a)))); }
+float hlum(H3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
+
+// rgb_to_radiometric, src/renderer.cu:146-162 (same operation order as the kernel used to run per sample)
+H3 h_rgb_to_radiometric(H3 color, float intensity) {
+    float m = sqrtf(hdot(color, color));
+    H3 cn{1, 1, 1};
+    if ((double)m > 1e-12) cn = hscale(color, (float)(1.0 / (double)m));
+    float photometric = intensity * m;
+    float alpha = (float)((double)photometric / (683.0 * (double)hlum(cn)));
+    return hscale(cn, alpha);
+}
 
 } // namespace
 
@@ -127,6 +138,9 @@ struct pt_context {
     DeviceArray<GMaterial> materials;
     DeviceArray<pt_light> lights;
     DeviceArray<pt_lst_node> lst;
+    DeviceArray<GLight> glights;
+    std::vector<pt_light> h_lights;
+    std::vector<GMaterial> h_materials;
     DeviceArray<Texture> textures;
     std::vector<void *> texel_blocks;
     size_t texel_bytes = 0;
@@ -216,6 +230,7 @@ extern "C" void pt_destroy(pt_context *ctx) {
     ctx->materials.release();
     ctx->lights.release();
     ctx->lst.release();
+    ctx->glights.release();
     ctx->textures.release();
     for (void *p : ctx->texel_blocks) (void)hipFree(p);
     ctx->jump.release();
@@ -256,6 +271,8 @@ extern "C" int pt_scene_upload(pt_context *ctx, const pt_scene_desc *scene) {
     if (ctx->shade.upload(ctx->h_shade.data(), ctx->h_shade.size())) return 1;
     if (ctx->materials.upload(mats.data(), mats.size())) return 1;
     if (ctx->lights.upload(scene->lights, scene->light_count)) return 1;
+    ctx->h_materials = mats;
+    ctx->h_lights.assign(scene->lights, scene->lights + scene->light_count);
 
     for (void *p : ctx->texel_blocks) (void)hipFree(p);
     ctx->texel_blocks.clear();
@@ -354,6 +371,47 @@ extern "C" int pt_lst_upload(pt_context *ctx, const pt_lst_node *nodes, uint32_t
     if (ctx->shade.upload(ctx->h_shade.data(), ctx->h_shade.size())) return 1;
     ctx->P.shade = ctx->shade.ptr;
     if (ctx->lst.upload(nodes, count)) return 1;
+    std::vector<GLight> gl(count);
+    uint32_t face_nodes = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        GLight g;
+        memset(&g, 0, sizeof(g));
+        if (nodes[i].type == PT_LST_SOURCE_LIGHT) {
+            const pt_light &L = ctx->h_lights[nodes[i].index];
+            H3 rad = h_rgb_to_radiometric(H3{L.color.x, L.color.y, L.color.z}, L.intensity);
+            g.radiance[0] = rad.x; g.radiance[1] = rad.y; g.radiance[2] = rad.z;
+            if (L.type == PT_LIGHT_POINT) {
+                g.kind = 0;
+                g.a[0] = L.position.x; g.a[1] = L.position.y; g.a[2] = L.position.z;
+            } else {
+                g.kind = 1;
+                H3 d = hunit(H3{-L.direction.x, -L.direction.y, -L.direction.z}); // renderer.cu:211-212
+                g.a[0] = d.x; g.a[1] = d.y; g.a[2] = d.z;
+            }
+        } else {
+            face_nodes++;
+            const GShade &sh = ctx->h_shade[nodes[i].index];
+            g.kind = 2;
+            g.face = nodes[i].index;
+            H3 A{sh.pos[0][0], sh.pos[0][1], sh.pos[0][2]}, B{sh.pos[1][0], sh.pos[1][1], sh.pos[1][2]};
+            H3 C{sh.pos[2][0], sh.pos[2][1], sh.pos[2][2]};
+            memcpy(g.a, sh.pos[0], 12);
+            memcpy(g.b, sh.pos[1], 12);
+            memcpy(g.c, sh.pos[2], 12);
+            H3 tri_cross = hcross(hsub(C, B), hsub(A, B)); // renderer.cu:102-105
+            float len = sqrtf(hdot(tri_cross, tri_cross));
+            H3 nrm = hscale(tri_cross, (float)(1.0 / (double)len));
+            g.normal[0] = nrm.x; g.normal[1] = nrm.y; g.normal[2] = nrm.z;
+            g.area = (float)(0.5 * (double)len);
+            const GMaterial &m = ctx->h_materials[sh.material];
+            H3 rad = h_rgb_to_radiometric(H3{m.emissive[0], m.emissive[1], m.emissive[2]}, 1.0f); // renderer.cu:242
+            g.radiance[0] = rad.x; g.radiance[1] = rad.y; g.radiance[2] = rad.z;
+        }
+        gl[i] = g;
+    }
+    if (ctx->glights.upload(gl.data(), gl.size())) return 1;
+    ctx->P.glights = ctx->glights.ptr;
+    ctx->P.lst_face_nodes = face_nodes;
     ctx->P.lst = ctx->lst.ptr;
     ctx->P.lst_count = count;
     ctx->have_lst = true;
@@ -508,5 +566,5 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
 extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
     if (!ctx) return 0;
     return ctx->nodes.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
-           ctx->lst.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes();
+           ctx->lst.bytes() + ctx->glights.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes();
 }

@@ -35,5 +35,13 @@ for b in range(a.batches):
     ms = r.last_kernel_ms()
     print(f"batch {b}: {ms:.3f} ms  {a.res * a.res * a.spp / ms / 1e3:.2f} Msamples/s", flush=True)
 if a.count:
-    print(r.count_batch(42, a.spp))
+    import time
+    t0 = time.perf_counter()
+    c = r.count_batch(42, a.spp)
+    dt = time.perf_counter() - t0
+    print(c)
+    if "wave_ticks" in c:
+        # s_memtime ticks at 100 MHz (constant clock): wave-seconds resident / (slots * kernel time)
+        print(f"instrumented launch {dt*1e3:.1f} ms; wave-seconds {c['wave_ticks']/1e8:.2f}; "
+              f"mean resident waves {c['wave_ticks']/1e8/dt:.0f}")
 r.close()

@@ -106,17 +106,17 @@ def main():
     barrier()
 
     # ---- timed region: K batches per rank + one reduce ---------------------------------------
-    kernel_ms = []
     t0 = time.perf_counter()
     prev = 0
     for j in range(args.steps):
         b = j * world + rank
         r.render_batch_into(acc.data_ptr(), SEED + b, prev, SPP_PER_STEP, stream)
         prev += SPP_PER_STEP
-        kernel_ms.append(r.last_kernel_ms())  # waits for that launch (HIP events on its stream)
     render.combine(acc, prev, prev * world)
     barrier()
     elapsed = time.perf_counter() - t0
+    # HIP events the library recorded around every launch, on the stream it was launched on
+    kernel_ms = [r.kernel_ms(k) for k in range(min(args.steps, 64))]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

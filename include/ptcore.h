@@ -78,7 +78,13 @@ int pt_lst_upload(pt_context *ctx, const pt_lst_node *nodes, uint32_t count);
  * leaves it uninitialised and relies on garbage * 0). */
 int pt_configure(pt_context *ctx, const pt_render_config *cfg);
 
-/* render_kernel<<<grid, block>>>(d_img, d_bvh, d_scene, d_lst, cfg, prev, cur)
+/* Launch order: the kernel renders one 8x8 pixel tile per wavefront. Every launch records how
+ * long each tile kept its wave slot, and the next launch of the context dispatches the tiles
+ * heaviest first (the reference's fixed 16x16 block order, src/main.cu:85-88, leaves the device
+ * draining behind its slowest blocks). Pixels do not depend on the order. PT_LPT=0 in the
+ * environment disables the reordering.
+ *
+ * render_kernel<<<grid, block>>>(d_img, d_bvh, d_scene, d_lst, cfg, prev, cur)
  * + cudaDeviceSynchronize — src/main.cu:104-106, src/renderer.cu:361-405.
  * `seed` is cfg.seed of that launch (the host loop adds 1 per batch,
  * src/main.cu:121). Blocking. Accumulates into the library-owned image. */
@@ -116,6 +122,11 @@ int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt_counters *
 /* HIP-event duration (ms) of the most recent render launch of this context,
  * measured on the stream it was launched on; waits for that launch. */
 float pt_last_kernel_ms(pt_context *ctx);
+
+/* Same for the render launch `launches_back` launches before the most recent one (0 = most
+ * recent, at most 63): lets a caller time a whole loop without waiting inside it. -1 if there is
+ * no such launch. */
+float pt_kernel_ms(pt_context *ctx, int launches_back);
 
 /* Bytes of device memory held by the context (scene + BVH + LST + image). */
 uint64_t pt_device_footprint(pt_context *ctx);

@@ -184,6 +184,8 @@ def core_lib():
     L.pt_count_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CoreCounters)]
     L.pt_last_kernel_ms.argtypes = [C.c_void_p]
     L.pt_last_kernel_ms.restype = C.c_float
+    L.pt_kernel_ms.argtypes = [C.c_void_p, C.c_int]
+    L.pt_kernel_ms.restype = C.c_float
     L.pt_device_footprint.argtypes = [C.c_void_p]
     L.pt_device_footprint.restype = C.c_uint64
     _core = L

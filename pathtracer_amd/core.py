@@ -98,6 +98,10 @@ class Renderer:
     def last_kernel_ms(self):
         return float(self._lib.pt_last_kernel_ms(self._ctx))
 
+    def kernel_ms(self, launches_back=0):
+        """HIP-event duration of an earlier render launch (0 = the most recent one)."""
+        return float(self._lib.pt_kernel_ms(self._ctx, int(launches_back)))
+
     def device_footprint(self):
         return int(self._lib.pt_device_footprint(self._ctx))
 

@@ -100,6 +100,9 @@ struct KernelParams {
     uint32_t seed_lo, seed_hi;
     int32_t previous_samples, current_samples;
     int32_t jitter; // primary-hit probe only
+    // launch order of the 8x8 tiles (heaviest first, from the previous launch's per-tile cost); both may be null
+    const uint32_t *tile_order;
+    uint32_t *tile_cost;
 };
 
 // ---- XORWOW ------------------------------------------------------------------------
@@ -418,6 +421,18 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
 #ifndef PT_SLICE
 #define PT_SLICE 16
 #endif
+#ifndef PT_SHADE_NUM
+#define PT_SHADE_NUM 0 /* shade when finished lanes / live lanes >= NUM / DEN (0 = as soon as any lane finished) */
+#endif
+#ifndef PT_PHASE
+#define PT_PHASE 1 /* serve one result handler per round: the mode most finished lanes are in */
+#endif
+#ifndef PT_PHASE_MINOR
+#define PT_PHASE_MINOR 65 /* the minority mode is served too once it has this many finished lanes */
+#endif
+#ifndef PT_SHADE_DEN
+#define PT_SHADE_DEN 4
+#endif
 #ifndef PT_BLOCKED_SHIFT
 #define PT_BLOCKED_SHIFT 1 /* leave the node loop when blocked lanes >= stepping lanes >> shift */
 #endif
@@ -640,22 +655,58 @@ PT_DEV float area_pdf(const GShade *s, f3 dir, float t, f3 *normal_out) {
     return t * t / (area * cos_theta_y);
 }
 
-PT_DEV void pixel_of_thread(const KernelParams &P, int *px, int *py) {
+PT_DEV uint32_t pixel_of_thread(const KernelParams &P, int *px, int *py) {
     // One wave64 renders one 8x8 pixel tile, so its 64 primary rays stay close. With
     // one-wave workgroups the dispatcher balances at tile granularity (a 16x16 block of four
     // waves left 38 % of the wave slots empty in the tail of a launch). Workgroups that share
     // blockIdx % 8 share an XCD and its L2: XCD x takes tile rows x, x+8, ..., so every XCD
     // sees the whole picture (balance) while horizontal neighbours stay on one L2.
+    // Once a launch has recorded per-tile costs, tile_order lists the tiles heaviest first
+    // (longest-processing-time-first): the dispatcher hands out workgroups in index order, so
+    // the expensive tiles start early and the cheap ones fill the tail.
     uint32_t ntx = ((uint32_t)P.width + 7u) / 8u, nty = ((uint32_t)P.height + 7u) / 8u;
     uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     uint32_t tx = wave % ntx, ty = wave / ntx;
-    if (nty % 8u == 0) {
+    if (P.tile_order) {
+        uint32_t t = P.tile_order[wave];
+        tx = t % ntx;
+        ty = t / ntx;
+    } else if (nty % 8u == 0) {
         uint32_t xcd = wave % 8u, i = wave / 8u;
         tx = i % ntx;
         ty = (i / ntx) * 8u + xcd;
     }
     *px = (int)(tx * 8u + (lane & 7u));
     *py = (int)(ty * 8u + (lane >> 3));
+    return ty * ntx + tx;
+}
+
+// order[rank] = tile, rank = position of the tile when sorted by (cost descending, index ascending).
+// PT_LPT_MODE 2 ranks within the tile-row class ty % 8 (the XCD a tile ran on by default) and
+// interleaves the classes, so a tile keeps its XCD; mode 1 ranks globally.
+#ifndef PT_LPT_MODE
+#define PT_LPT_MODE 1
+#endif
+__global__ void __launch_bounds__(256) tile_rank_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order,
+                                                        uint32_t n, uint32_t ntx, uint32_t classes) {
+    __shared__ uint32_t chunk[256];
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t mine = i < n ? cost[i] : 0u;
+    uint32_t my_class = classes > 1 ? (i / ntx) % classes : 0u;
+    uint32_t rank = 0;
+    for (uint32_t base = 0; base < n; base += 256u) {
+        uint32_t j = base + threadIdx.x;
+        chunk[threadIdx.x] = j < n ? cost[j] : 0u;
+        __syncthreads();
+        uint32_t m = n - base < 256u ? n - base : 256u;
+        for (uint32_t k = 0; k < m; k++) {
+            uint32_t c = chunk[k], jj = base + k;
+            bool same = classes > 1 ? ((jj / ntx) % classes == my_class) : true;
+            rank += (same && (c > mine || (c == mine && jj < i))) ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    if (i < n) order[classes > 1 ? rank * classes + my_class : rank] = i;
 }
 
 PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {
@@ -676,7 +727,8 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
     uint32_t *stack = lds_stack + threadIdx.x;
 
     int px, py;
-    pixel_of_thread(P, &px, &py);
+    const uint32_t tile = pixel_of_thread(P, &px, &py);
+    const unsigned long long t_tile0 = P.tile_cost ? __builtin_amdgcn_s_memtime() : 0ull;
     bool inside = px < P.width && py < P.height;
     Tally n = {};
     if (COUNT) {
@@ -746,7 +798,24 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
         }
         walk_slice<COUNT, STACK>(P, ro, rd, t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
-        if (wk.ref != kDone || wk.pleaf != 0) continue; // still walking: next slice
+        const bool finished = wk.ref == kDone && wk.pleaf == 0;
+#if PT_SHADE_NUM > 0
+        { // shade only once enough of the wave's live lanes have a result (wave-uniform decision)
+            int n_fin = __builtin_popcountll(__builtin_amdgcn_ballot_w64(finished));
+            int n_live = __builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+            if (n_fin != n_live && n_fin * PT_SHADE_DEN < n_live * PT_SHADE_NUM) continue;
+        }
+#endif
+#if PT_PHASE > 0
+        { // main-ray and shadow-ray results take different handlers: serve the mode most finished lanes are in
+            int n_main = __builtin_popcountll(__builtin_amdgcn_ballot_w64(finished && mode == kModeMain));
+            int n_nee = __builtin_popcountll(__builtin_amdgcn_ballot_w64(finished && mode == kModeNee));
+            bool take_main = n_main >= n_nee;
+            int n_minor = take_main ? n_nee : n_main;
+            if (finished && (mode == kModeMain) != take_main && n_minor < PT_PHASE_MINOR) continue; // wait a round
+        }
+#endif
+        if (!finished) continue; // still walking: next slice
         walking = false;
         unsigned long long tsh0 = stamp<COUNT>();
         HitLite hit = wk.h;
@@ -1008,6 +1077,10 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
             p[1] = next.y;
             p[2] = next.z;
         }
+    }
+    if (P.tile_cost && (threadIdx.x & 63) == 0) { // ticks this tile kept a wave slot busy, clamped to 32 bits
+        unsigned long long dt = __builtin_amdgcn_s_memtime() - t_tile0;
+        P.tile_cost[tile] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
     }
     if (COUNT && counters) {
         atomicAdd(&counters[0], (unsigned long long)n.samples);

@@ -125,8 +125,10 @@ H3 h_rgb_to_radiometric(H3 color, float intensity) {
 struct pt_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timed = false;
+    // HIP events around the last kEventRing render launches (pt_kernel_ms)
+    static constexpr int kEventRing = 64;
+    hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
+    uint64_t launches = 0;
 
     // host copies needed across uploads
     std::vector<GShade> h_shade;
@@ -147,6 +149,8 @@ struct pt_context {
     DeviceArray<uint32_t> jump;
     DeviceArray<float> image;
     DeviceArray<unsigned long long> counters;
+    DeviceArray<uint32_t> tile_cost, tile_order; // one entry per 8x8 tile
+    bool order_valid = false;                    // tile_order holds a permutation for this resolution
 
     bool have_scene = false, have_bvh = false, have_lst = false, have_cfg = false;
     uint32_t face_count = 0, light_count = 0;
@@ -178,6 +182,22 @@ void set_launch(pt_context *ctx, int seed, int prev, int cur, int jitter) {
     ctx->P.previous_samples = prev;
     ctx->P.current_samples = cur;
     ctx->P.jitter = jitter;
+    ctx->P.tile_order = nullptr; // launch_render opts in
+    ctx->P.tile_cost = nullptr;
+}
+
+// PT_LPT=0 in the environment keeps the static tile order (A/B measurements)
+const bool g_lpt = []() { const char *e = getenv("PT_LPT"); return !(e && e[0] == '0'); }();
+
+// Ranks the tiles by the cost the launch before it recorded (same stream, so ordered after it).
+void launch_rank(pt_context *ctx, hipStream_t st) {
+    if (!g_lpt) return;
+    uint32_t ntx = ((uint32_t)ctx->P.width + 7u) / 8u, nty = ((uint32_t)ctx->P.height + 7u) / 8u;
+    uint32_t n = ntx * nty;
+    uint32_t classes = (PT_LPT_MODE == 2 && nty % 8u == 0) ? 8u : 1u;
+    hipLaunchKernelGGL(tile_rank_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, ctx->tile_cost.ptr,
+                       ctx->tile_order.ptr, n, ntx, classes);
+    ctx->order_valid = true;
 }
 
 dim3 grid_of(const pt_context *ctx) {
@@ -188,6 +208,8 @@ dim3 grid_of(const pt_context *ctx) {
 
 template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned long long *counters, hipStream_t st) {
     dim3 grid = grid_of(ctx), block(kBlock);
+    ctx->P.tile_order = (ctx->order_valid && g_lpt) ? ctx->tile_order.ptr : nullptr;
+    ctx->P.tile_cost = g_lpt ? ctx->tile_cost.ptr : nullptr;
     if (ctx->bvh_height <= 33)
         hipLaunchKernelGGL((render_kernel<COUNT, 32>), grid, block, 0, st, ctx->P, img, counters);
     else
@@ -209,8 +231,10 @@ extern "C" int pt_create(int device, pt_context **out) {
     ctx->device = device;
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&ctx->ev_start));
-    HIP_TRY(hipEventCreate(&ctx->ev_stop));
+    for (int i = 0; i < pt_context::kEventRing; i++) {
+        HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
+        HIP_TRY(hipEventCreate(&ctx->ev_stop[i]));
+    }
     std::vector<uint32_t> tables = build_jump_tables();
     if (ctx->jump.upload(tables.data(), tables.size())) return 1;
     unsigned long long zeros[32] = {0};
@@ -236,8 +260,12 @@ extern "C" void pt_destroy(pt_context *ctx) {
     ctx->jump.release();
     ctx->image.release();
     ctx->counters.release();
-    (void)hipEventDestroy(ctx->ev_start);
-    (void)hipEventDestroy(ctx->ev_stop);
+    ctx->tile_cost.release();
+    ctx->tile_order.release();
+    for (int i = 0; i < pt_context::kEventRing; i++) {
+        if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
+        if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -438,6 +466,15 @@ extern "C" int pt_configure(pt_context *ctx, const pt_render_config *cfg) {
         HIP_TRY(hipMalloc((void **)&ctx->image.ptr, n * sizeof(float)));
     }
     HIP_TRY(hipMemset(ctx->image.ptr, 0, n * sizeof(float)));
+    size_t tiles = (size_t)((P.width + 7) / 8) * (size_t)((P.height + 7) / 8);
+    if (ctx->tile_cost.count != tiles) {
+        ctx->tile_cost.release();
+        ctx->tile_order.release();
+        ctx->tile_cost.count = ctx->tile_order.count = tiles;
+        HIP_TRY(hipMalloc((void **)&ctx->tile_cost.ptr, tiles * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&ctx->tile_order.ptr, tiles * sizeof(uint32_t)));
+        ctx->order_valid = false;
+    }
     ctx->have_cfg = true;
     return 0;
 }
@@ -457,11 +494,14 @@ extern "C" int pt_render_batch_into(pt_context *ctx, float *device_img, void *st
     if (current_samples <= 0 || previous_samples < 0) return fail("pt_render_batch: bad sample counts (%d, %d)", previous_samples, current_samples);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     set_launch(ctx, seed, previous_samples, current_samples, 1);
-    HIP_TRY(hipEventRecord(ctx->ev_start, st));
+    const int slot = (int)(ctx->launches % pt_context::kEventRing);
+    HIP_TRY(hipEventRecord(ctx->ev_start[slot], st));
     launch_render<false>(ctx, device_img, nullptr, st);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev_stop, st));
-    ctx->timed = true;
+    HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));
+    launch_rank(ctx, st);
+    HIP_TRY(hipGetLastError());
+    ctx->launches++;
     return 0;
 }
 
@@ -478,14 +518,17 @@ extern "C" int pt_synchronize(pt_context *ctx) {
     return 0;
 }
 
-extern "C" float pt_last_kernel_ms(pt_context *ctx) {
-    if (!ctx || !ctx->timed) return -1.f;
+extern "C" float pt_kernel_ms(pt_context *ctx, int launches_back) {
+    if (!ctx || launches_back < 0 || launches_back >= pt_context::kEventRing || (uint64_t)launches_back >= ctx->launches) return -1.f;
     if (hipSetDevice(ctx->device) != hipSuccess) return -1.f;
-    if (hipEventSynchronize(ctx->ev_stop) != hipSuccess) return -1.f;
+    const int slot = (int)((ctx->launches - 1 - (uint64_t)launches_back) % pt_context::kEventRing);
+    if (hipEventSynchronize(ctx->ev_stop[slot]) != hipSuccess) return -1.f;
     float ms = -1.f;
-    if (hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]) != hipSuccess) return -1.f;
     return ms;
 }
+
+extern "C" float pt_last_kernel_ms(pt_context *ctx) { return pt_kernel_ms(ctx, 0); }
 
 extern "C" int pt_read_image(pt_context *ctx, float *host_rgb) {
     if (bind(ctx)) return 1;
@@ -566,5 +609,6 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
 extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
     if (!ctx) return 0;
     return ctx->nodes.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
-           ctx->lst.bytes() + ctx->glights.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes();
+           ctx->lst.bytes() + ctx->glights.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes() +
+           ctx->tile_cost.bytes() + ctx->tile_order.bytes();
 }

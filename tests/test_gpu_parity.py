@@ -86,6 +86,18 @@ def test_running_mean_over_batches(renderer, cornell_like):
     _assert_images_match(gpu, cpu)
 
 
+def test_tile_reordering_keeps_pixels(renderer, scene_dir):
+    """From the second launch on the tiles are dispatched heaviest-first (per-tile cost of the
+    previous launch); every pixel must still come out as in the oracle, at a size with more
+    tiles than wave slots per CU and a ragged right/top edge."""
+    b = util.load_bundle(scenes.write_many_lights_standin(scene_dir, rings=40, segments=64, name="ml_small"))
+    w, h = 200, 136
+    o = _setup(renderer, b, w, h)
+    gpu = renderer.render(5, 8, 2)  # four launches: static order, then three re-ranked ones
+    cpu = o.render(5, 8, 2)
+    _assert_images_match(gpu, cpu)
+
+
 def test_golden_cornell_c1(renderer):
     """BASELINE config 1 (cornell.gltf 256x256, 16 spp, seed 42) on the reference's own scene,
     carried to the GPU box as derived arrays."""

@@ -38,15 +38,20 @@ typedef struct {
     uint64_t shaded_hits;
     uint64_t bounces;
     /* Wave-level occupancy of six code regions, in order: state-machine loop, inner-node
-     * step, leaf step, main-ray handler, shadow-ray handler, BSDF sampling. iters = times a
-     * wave executed the region, lanes = sum of lanes active in it (64 * iters = full). */
+     * step, leaf step, path-vertex handler (main-ray result), shadow-ray result, BSDF sampling
+     * (inside the vertex handler). iters = times a wave executed the region, lanes = sum of
+     * lanes active in it (64 * iters = full). */
     uint64_t region_iters[6];
     uint64_t region_lanes[6];
     /* Shader-clock ticks summed over waves: [0] inside the walk slices, [1] node phases,
-     * [2] leaf phases, [3] result handling + shading + next-ray set-up, [4],[5] unused;
+     * [2] leaf phases, [3] path-vertex handler, [4] shadow-ray results, [5] unused;
      * wave_ticks = sum of wave lifetimes (includes RNG init and the image write). */
     uint64_t region_ticks[6];
     uint64_t wave_ticks;
+    /* Lanes that sat out the wave's inner-node steps, summed over steps: [0] standing on a leaf
+     * with another one parked, [1] walk finished except for a parked leaf, [2] walk finished,
+     * waiting for its result handler. (Lanes whose pixel is complete are 64*iters - lanes - these.) */
+    uint64_t node_step_idle[3];
 } pt_counters;
 
 const char *pt_last_error(void);

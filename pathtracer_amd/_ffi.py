@@ -79,7 +79,8 @@ class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
     _fields_ = [(n, C.c_uint64) for n in
                 ("samples", "rays", "inner_visits", "tri_tests", "traversals", "shaded_hits", "bounces")] + \
                [("region_iters", C.c_uint64 * 6), ("region_lanes", C.c_uint64 * 6),
-                ("region_ticks", C.c_uint64 * 6), ("wave_ticks", C.c_uint64)]
+                ("region_ticks", C.c_uint64 * 6), ("wave_ticks", C.c_uint64),
+                ("node_step_idle", C.c_uint64 * 3)]
     REGIONS = ("loop", "inner", "leaf", "main", "nee", "bsdf")
 
     def as_dict(self):
@@ -87,8 +88,14 @@ class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
         d["lane_utilisation"] = {r: round(self.region_lanes[i] / (64.0 * self.region_iters[i]), 4) if self.region_iters[i] else None
                                  for i, r in enumerate(self.REGIONS)}
         d["wave_iterations"] = {r: int(self.region_iters[i]) for i, r in enumerate(self.REGIONS)}
+        if self.region_iters[1]:
+            tot = 64.0 * self.region_iters[1]
+            d["node_step_lanes"] = {"stepping": round(self.region_lanes[1] / tot, 4),
+                                    "blocked_on_leaves": round(self.node_step_idle[0] / tot, 4),
+                                    "parked_leaf_only": round(self.node_step_idle[1] / tot, 4),
+                                    "awaiting_handler": round(self.node_step_idle[2] / tot, 4)}
         if self.wave_ticks:
-            names = ("walk_slices", "node_phases", "leaf_phases", "shading")
+            names = ("walk_slices", "node_phases", "leaf_phases", "vertex_handler", "shadow_results")
             d["time_share"] = {nm: round(self.region_ticks[i] / self.wave_ticks, 4) for i, nm in enumerate(names)}
             d["wave_ticks"] = int(self.wave_ticks)
         return d

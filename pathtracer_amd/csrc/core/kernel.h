@@ -264,6 +264,7 @@ struct Tally {
     // wave-level occupancy of each code region (instrumented variant only): iterations executed by
     // the wave, and the sum of lanes that were active in them
     uint32_t w_iters[6], w_lanes[6];
+    uint32_t w_idle[3]; // lanes that sat out a node step: blocked on two leaves | walk over but for a parked leaf | waiting for a handler
     unsigned long long *w_time; // LDS: shader-clock ticks per region, written by the wave's leader lane
 };
 enum : int { kRegLoop = 0, kRegInner = 1, kRegLeaf = 2, kRegMain = 3, kRegNee = 4, kRegBsdf = 5 };
@@ -424,12 +425,6 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
 #ifndef PT_SHADE_NUM
 #define PT_SHADE_NUM 0 /* shade when finished lanes / live lanes >= NUM / DEN (0 = as soon as any lane finished) */
 #endif
-#ifndef PT_PHASE
-#define PT_PHASE 1 /* serve one result handler per round: the mode most finished lanes are in */
-#endif
-#ifndef PT_PHASE_MINOR
-#define PT_PHASE_MINOR 65 /* the minority mode is served too once it has this many finished lanes */
-#endif
 #ifndef PT_SHADE_DEN
 #define PT_SHADE_DEN 4
 #endif
@@ -504,6 +499,15 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
             int n_step = __builtin_popcountll(m_step), n_blocked = __builtin_popcountll(m_blocked);
             if (n_step == 0 || steps >= PT_SLICE || (n_blocked != 0 && n_blocked >= (n_step >> PT_BLOCKED_SHIFT))) break;
             steps++;
+            if (COUNT) {
+                unsigned long long m_parked = __builtin_amdgcn_ballot_w64(w.ref == kDone && w.pleaf != 0);
+                unsigned long long m_fin = __builtin_amdgcn_ballot_w64(w.ref == kDone && w.pleaf == 0);
+                if (stepping && __builtin_amdgcn_mbcnt_hi((unsigned)(m_step >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_step, 0)) == 0) {
+                    n.w_idle[0] += (uint32_t)n_blocked;
+                    n.w_idle[1] += (uint32_t)__builtin_popcountll(m_parked);
+                    n.w_idle[2] += (uint32_t)__builtin_popcountll(m_fin);
+                }
+            }
             if (stepping) {
                 const float4 *np = (const float4 *)(P.nodes + w.ref);
                 float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
@@ -743,15 +747,19 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
     f3 total = mk3(0, 0, 0);
     f3 light = mk3(0, 0, 0), thr = mk3(1, 1, 1);
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
-    Vertex vx = {};
     float rr_prob = 1.f;
     f3 f_cos_next = mk3(0, 0, 0); // BSDF sample's f*cos, applied once p_direct is known
     bool pending = false;         // a BSDF sample is waiting for the next hit to finish its MIS weight
-    // NEE state carried across the shadow walk
-    f3 nee_dir = mk3(0, 0, 0), nee_radiance = mk3(0, 0, 0);
-    float nee_p = 0.f, nee_dist = 0.f;
+    // Carried across a shadow walk. Every random draw of a path vertex (light choice, point on the
+    // emitter, BSDF direction) precedes both of its rays in the reference (renderer.cu:330-351), and
+    // the distance at which a visible emitter is met is known beforehand (t_f below), so the vertex
+    // handler finishes ALL of the vertex's arithmetic: the MIS-weighted direct term as it would be
+    // if the light is visible (direct_c) and the next bounce ray (rd_next). The shadow walk only
+    // answers "visible?", and its result needs no second heavy handler.
+    f3 rd_next = mk3(0, 0, 1), direct_c = mk3(0, 0, 0);
+    float nee_dist = 0.f;
     int nee_kind = 0; // 0 point, 1 directional, 2 area
-    uint32_t nee_light = 0;
+    int32_t nee_face = -1;
     float t_init = kNoHit, t_stop = -1.0f; // limits of the next walk (see kBand)
     Walk wk = {};
     bool walking = false;
@@ -779,7 +787,6 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
 
         region_tick<COUNT>(n, kRegLoop);
         unsigned long long tl0 = stamp<COUNT>();
-#if PT_SLICE > 0
         if (!walking) { // start the walk of the ray set up by the previous iteration
             wk.ref = P.root;
             wk.pleaf = 0;
@@ -799,263 +806,254 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
         walk_slice<COUNT, STACK>(P, ro, rd, t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
         const bool finished = wk.ref == kDone && wk.pleaf == 0;
+
+        if (finished && mode == kModeNee) {
+            unsigned long long tn0 = stamp<COUNT>();
+            // ---- shadow walk finished: visibility only (sample_light_source, renderer.cu:193-247) ----
+            region_tick<COUNT>(n, kRegNee);
+            if (COUNT) n.rays++;
+            bool visible;
+            if (nee_kind == 0) {
+                float closest = wk.h.face >= 0 ? wk.h.t : kNoHit;
+                visible = !wk.h.early && nee_dist < closest;
+            } else if (nee_kind == 1) {
+                visible = wk.h.face < 0;
+            } else { // met the emitter itself, in front of the origin, nothing nearer (then wk.h.t == t_f)
+                visible = !wk.h.early && wk.h.face == nee_face && wk.h.t > 0;
+            }
+            if (visible) light = light + direct_c;
+            rd = rd_next; // same origin (renderer.cu:203, :350)
+            pending = true;
+            mode = kModeMain;
+            t_init = kNoHit;
+            t_stop = -1.0f;
+            walking = false;
+            region_time<COUNT>(n, kRegNee, tn0, stamp<COUNT>());
+            continue;
+        }
 #if PT_SHADE_NUM > 0
-        { // shade only once enough of the wave's live lanes have a result (wave-uniform decision)
+        { // run the vertex handler only once enough of the wave's live lanes wait for it (wave-uniform)
             int n_fin = __builtin_popcountll(__builtin_amdgcn_ballot_w64(finished));
             int n_live = __builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
             if (n_fin != n_live && n_fin * PT_SHADE_DEN < n_live * PT_SHADE_NUM) continue;
         }
 #endif
-#if PT_PHASE > 0
-        { // main-ray and shadow-ray results take different handlers: serve the mode most finished lanes are in
-            int n_main = __builtin_popcountll(__builtin_amdgcn_ballot_w64(finished && mode == kModeMain));
-            int n_nee = __builtin_popcountll(__builtin_amdgcn_ballot_w64(finished && mode == kModeNee));
-            bool take_main = n_main >= n_nee;
-            int n_minor = take_main ? n_nee : n_main;
-            if (finished && (mode == kModeMain) != take_main && n_minor < PT_PHASE_MINOR) continue; // wait a round
-        }
-#endif
         if (!finished) continue; // still walking: next slice
-        walking = false;
         unsigned long long tsh0 = stamp<COUNT>();
+        walking = false;
         HitLite hit = wk.h;
         if (hit.face < 0) hit.t = kNoHit;
-#else
-        HitLite hit = trace<COUNT, STACK>(P, ro, rd, t_init, t_stop, stack, n);
-#endif
 
-        bool do_bsdf = false;
+        // ---- main-ray result: one handler per path vertex ----
+        region_tick<COUNT>(n, kRegMain);
+        if (COUNT) n.rays++;
         bool end_path = false;
-        bool skip_nee = false;
-        if (mode == kModeMain) {
-            region_tick<COUNT>(n, kRegMain);
-            if (COUNT) n.rays++;
-            const bool sh = hit.face >= 0;
-            GShade s;
-            GMaterial m;
-            if (sh) { // both records are addressed by the walk's result, so the two fetches overlap
-                s = P.shade[hit.face];
-                m = P.materials[hit.material];
-            }
-            if (pending) {
-                // evaluate_direct_p: only the LST node whose face this ray hit contributes
-                float p_direct = 0.f;
-                if (P.lst_count != 0) {
-                    if (sh && (s.flags & kShadeIsLight) && hit.t > 0) {
-                        // a face listed k times in the LST contributes k equal terms
-                        float p_als = area_pdf(&s, rd, hit.t, nullptr);
-                        for (uint32_t k = s.flags >> 8; k > 0; k--) p_direct += p_als;
-                    }
-                    p_direct = p_direct / (float)P.lst_count;
+        const bool sh = hit.face >= 0;
+        GShade s;
+        GMaterial m;
+        if (sh) { // both records are addressed by the walk's result, so the two fetches overlap
+            s = P.shade[hit.face];
+            m = P.materials[hit.material];
+        }
+        if (pending) {
+            // evaluate_direct_p: only the LST node whose face this ray hit contributes
+            float p_direct = 0.f;
+            if (P.lst_count != 0) {
+                if (sh && (s.flags & kShadeIsLight) && hit.t > 0) {
+                    // a face listed k times in the LST contributes k equal terms
+                    float p_als = area_pdf(&s, rd, hit.t, nullptr);
+                    for (uint32_t k = s.flags >> 8; k > 0; k--) p_direct += p_als;
                 }
-                float pdf = brdf_pdf();
-                float weight = pdf / (p_direct + pdf);
-                thr = thr * (f_cos_next * (weight / (pdf * rr_prob)));
-                pending = false;
+                p_direct = p_direct / (float)P.lst_count;
             }
-            if (!sh) {
-                f3 clear = ld3(P.clear_color);
-                if (P.clear_texture >= 0) {
-                    float phi = pt_atan2f(rd.z, rd.x);
-                    float theta = pt_acosf(min_gl(max_gl(rd.y, -1.0f), 1.0f));
-                    float eu = (float)(((double)phi + PT_PI_D) / (2.0f * PT_PI_D));
-                    float ev = (float)((double)theta / PT_PI_D);
-                    float4 t = sample_texture(P.textures + P.clear_texture, eu, ev);
-                    clear = clear * mk3(t.x, t.y, t.z);
+            float pdf = brdf_pdf();
+            float weight = pdf / (p_direct + pdf);
+            thr = thr * (f_cos_next * (weight / (pdf * rr_prob)));
+            pending = false;
+        }
+        if (!sh) {
+            f3 clear = ld3(P.clear_color);
+            if (P.clear_texture >= 0) {
+                float phi = pt_atan2f(rd.z, rd.x);
+                float theta = pt_acosf(min_gl(max_gl(rd.y, -1.0f), 1.0f));
+                float eu = (float)(((double)phi + PT_PI_D) / (2.0f * PT_PI_D));
+                float ev = (float)((double)theta / PT_PI_D);
+                float4 t = sample_texture(P.textures + P.clear_texture, eu, ev);
+                clear = clear * mk3(t.x, t.y, t.z);
+            }
+            light = light + thr * clear;
+            end_path = true;
+        } else {
+            // ---- hit record (intersect.cu:100-198) ----
+            float u = hit.u, v = hit.v;
+            float w = (float)(1.0 - (double)u - (double)v);
+            f3 position = (w * ld3(s.pos[0]) + u * ld3(s.pos[1])) + v * ld3(s.pos[2]);
+            f3 baseColor = mk3(m.baseColorFactor[0], m.baseColorFactor[1], m.baseColorFactor[2]);
+            float alpha = m.baseColorFactor[3];
+            float roughness = m.roughness, metallic = m.metallic;
+            if (m.baseColorTexture >= 0 || m.metallicRoughnessTexture >= 0) {
+                float tu = (w * s.uv[0][0] + u * s.uv[1][0]) + v * s.uv[2][0];
+                float tv = (w * s.uv[0][1] + u * s.uv[1][1]) + v * s.uv[2][1];
+                if (m.baseColorTexture >= 0) {
+                    float4 t = sample_texture(P.textures + m.baseColorTexture, tu, tv);
+                    baseColor = baseColor * mk3(t.x, t.y, t.z);
+                    alpha *= t.w;
                 }
-                light = light + thr * clear;
-                end_path = true;
+                if (m.metallicRoughnessTexture >= 0) {
+                    float4 t = sample_texture(P.textures + m.metallicRoughnessTexture, tu, tv);
+                    roughness *= t.y;
+                    metallic *= t.z;
+                }
+            }
+            if (m.alphaMode == PT_ALPHA_OPAQUE) alpha = 1.0f;
+            else if (m.alphaMode == PT_ALPHA_MASK) alpha = alpha > m.alphaCutoff ? 1.0f : 0.0f;
+
+            f3 normal, tangent;
+            if (s.flags & kShadeFlat) {
+                normal = ld3(s.nrm[0]);
+                tangent = ld3(s.tan[0]);
             } else {
-                // ---- hit record (intersect.cu:100-198) ----
-                float u = hit.u, v = hit.v;
-                float w = (float)(1.0 - (double)u - (double)v);
-                f3 position = (w * ld3(s.pos[0]) + u * ld3(s.pos[1])) + v * ld3(s.pos[2]);
-                f3 baseColor = mk3(m.baseColorFactor[0], m.baseColorFactor[1], m.baseColorFactor[2]);
-                float alpha = m.baseColorFactor[3];
-                float roughness = m.roughness, metallic = m.metallic;
-                if (m.baseColorTexture >= 0 || m.metallicRoughnessTexture >= 0) {
-                    float tu = (w * s.uv[0][0] + u * s.uv[1][0]) + v * s.uv[2][0];
-                    float tv = (w * s.uv[0][1] + u * s.uv[1][1]) + v * s.uv[2][1];
-                    if (m.baseColorTexture >= 0) {
-                        float4 t = sample_texture(P.textures + m.baseColorTexture, tu, tv);
-                        baseColor = baseColor * mk3(t.x, t.y, t.z);
-                        alpha *= t.w;
-                    }
-                    if (m.metallicRoughnessTexture >= 0) {
-                        float4 t = sample_texture(P.textures + m.metallicRoughnessTexture, tu, tv);
-                        roughness *= t.y;
-                        metallic *= t.z;
-                    }
-                }
-                if (m.alphaMode == PT_ALPHA_OPAQUE) alpha = 1.0f;
-                else if (m.alphaMode == PT_ALPHA_MASK) alpha = alpha > m.alphaCutoff ? 1.0f : 0.0f;
+                normal = (w * ld3(s.nrm[0]) + u * ld3(s.nrm[1])) + v * ld3(s.nrm[2]);
+                tangent = (w * ld3(s.tan[0]) + u * ld3(s.tan[1])) + v * ld3(s.tan[2]);
+            }
+            float handed = s.handed < 0 ? -1.0f : 1.0f;
+            f3 bitangent = handed * cross(normal, tangent);
+            tangent = normalize(tangent);
+            bitangent = normalize(bitangent);
+            normal = normalize(normal);
+            if (dot(normal, rd) > 0) {
+                tangent = tangent * -1.0f;
+                bitangent = bitangent * -1.0f;
+                normal = normal * -1.0f;
+            }
 
-                f3 normal, tangent;
-                if (s.flags & kShadeFlat) {
-                    normal = ld3(s.nrm[0]);
-                    tangent = ld3(s.tan[0]);
+            // ---- integrate_Li body (renderer.cu:309-355) ----
+            if (rng_uniform(rng) >= alpha) {
+                ro = position + 1e-6f * (-normal);
+                // direction unchanged; no RR, no throughput change (renderer.cu:310-314)
+            } else {
+                if (COUNT) n.shaded++;
+                light = light + ld3(m.emissive) * thr;
+                rr_prob = min_gl(luminance(thr), 0.99f);
+                if (rng_uniform(rng) >= rr_prob) {
+                    end_path = true;
                 } else {
-                    normal = (w * ld3(s.nrm[0]) + u * ld3(s.nrm[1])) + v * ld3(s.nrm[2]);
-                    tangent = (w * ld3(s.tan[0]) + u * ld3(s.tan[1])) + v * ld3(s.tan[2]);
-                }
-                float handed = s.handed < 0 ? -1.0f : 1.0f;
-                f3 bitangent = handed * cross(normal, tangent);
-                tangent = normalize(tangent);
-                bitangent = normalize(bitangent);
-                normal = normalize(normal);
-                if (dot(normal, rd) > 0) {
-                    tangent = tangent * -1.0f;
-                    bitangent = bitangent * -1.0f;
-                    normal = normal * -1.0f;
-                }
+                    Vertex vx;
+                    vx.position = position;
+                    vx.normal = normal;
+                    vx.tx = tangent;
+                    vx.ty = bitangent;
+                    vx.brdf.baseColor = baseColor;
+                    vx.brdf.roughness = roughness;
+                    vx.brdf.metallic = metallic;
+                    vx.brdf.specular = m.specular;
+                    vx.wo_ts = tbn_t_mul(vx, -rd);
 
-                // ---- integrate_Li body (renderer.cu:309-355) ----
-                if (rng_uniform(rng) >= alpha) {
-                    ro = position + 1e-6f * (-normal);
-                    // direction unchanged; no RR, no throughput change (renderer.cu:310-314)
-                } else {
-                    if (COUNT) n.shaded++;
-                    light = light + ld3(m.emissive) * thr;
-                    rr_prob = min_gl(luminance(thr), 0.99f);
-                    if (rng_uniform(rng) >= rr_prob) {
-                        end_path = true;
-                    } else {
-                        vx.position = position;
-                        vx.normal = normal;
-                        vx.tx = tangent;
-                        vx.ty = bitangent;
-                        vx.brdf.baseColor = baseColor;
-                        vx.brdf.roughness = roughness;
-                        vx.brdf.metallic = metallic;
-                        vx.brdf.specular = m.specular;
-                        vx.wo_ts = tbn_t_mul(vx, -rd);
-
-                        // ---- sample_light_source (renderer.cu:164-249) up to the shadow walk ----
-                        if (P.lst_count == 0) {
-                            do_bsdf = true;
+                    // ---- sample_light_source (renderer.cu:164-249), everything but the visibility walk ----
+                    bool shadow = false;
+                    f3 nee_dir = mk3(0, 0, 0);
+                    float s_init = kNoHit, s_stop = -1.0f;
+                    if (P.lst_count != 0) {
+                        int node_index = (int)((float)P.lst_count * rng_uniform(rng));
+                        GLight gl = P.glights[(uint32_t)node_index % P.lst_count];
+                        float p_lss = 1.0f / (float)P.lst_count; // times the area pdf for an emitter
+                        f3 radiance = ld3(gl.radiance);
+                        f3 A = ld3(gl.a), B = ld3(gl.b), C = ld3(gl.c);
+                        bool can_see = true; // false: the reference's walk cannot end on this light
+                        nee_kind = (int)gl.kind;
+                        if (gl.kind == 0) {
+                            f3 dl = A - position;
+                            float distance = length(dl);
+                            nee_dir = dl / distance;
+                            nee_dist = distance;
+                            radiance = radiance / (distance * distance);
+                            s_init = distance + distance * kBand;
+                            s_stop = distance - distance * kBand;
+                        } else if (gl.kind == 1) {
+                            nee_dir = A;
+                            s_init = kNoHit; // visible iff nothing at all is hit: stop at the first hit
+                            s_stop = kNoHit;
                         } else {
-                            int node_index = (int)((float)P.lst_count * rng_uniform(rng));
-                            nee_light = (uint32_t)node_index % P.lst_count;
-                            GLight gl = P.glights[nee_light];
-                            nee_p = 1.0f / (float)P.lst_count;
-                            nee_kind = (int)gl.kind;
-                            nee_radiance = ld3(gl.radiance);
-                            f3 A = ld3(gl.a), B = ld3(gl.b), C = ld3(gl.c);
-                            if (gl.kind == 0) {
-                                f3 dl = A - position;
-                                float distance = length(dl);
-                                nee_dir = dl / distance;
-                                nee_dist = distance;
-                                nee_radiance = nee_radiance / (distance * distance);
-                                t_init = distance + distance * kBand;
-                                t_stop = distance - distance * kBand;
-                            } else if (gl.kind == 1) {
-                                nee_dir = A;
-                                t_init = kNoHit; // visible iff nothing at all is hit: stop at the first hit
-                                t_stop = kNoHit;
-                            } else {
-                                float u1, u2;
-                                do {
-                                    u1 = rng_uniform(rng);
-                                    u2 = rng_uniform(rng);
-                                } while (u1 + u2 > 1);
-                                f3 light_pos = (A + u1 * (B - A)) + u2 * (C - A);
-                                nee_dir = normalize(light_pos - position);
-                                // distance at which this ray meets the emitter itself (same arithmetic as the
-                                // walk's triangle test); without such a hit the emitter cannot be the closest face
-                                f3 so = position + 1e-6f * normal;
-                                f3 e1 = B - A, e2 = C - A;
-                                f3 pvec = cross(nee_dir, e2);
-                                float det = dot(e1, pvec);
-                                float t_f = -1.0f;
-                                if (!(det > -PT_EPS_UP && det < PT_EPS_UP)) {
-                                    float inv_det = 1.0f / det;
-                                    f3 tvec = so - A;
-                                    float u = dot(tvec, pvec) * inv_det;
-                                    if (!(u <= -PT_EPS_UP || u > 1.0f)) {
-                                        f3 qvec = cross(tvec, e1);
-                                        float v = dot(nee_dir, qvec) * inv_det;
-                                        if (!(v <= -PT_EPS_UP || (u + v) > 1.0f)) t_f = dot(e2, qvec) * inv_det;
-                                    }
-                                }
-                                if (t_f > 0) {
-                                    t_init = t_f + t_f * kBand;
-                                    t_stop = t_f - t_f * kBand;
-                                } else {
-                                    skip_nee = true;
+                            float u1, u2;
+                            do {
+                                u1 = rng_uniform(rng);
+                                u2 = rng_uniform(rng);
+                            } while (u1 + u2 > 1);
+                            f3 light_pos = (A + u1 * (B - A)) + u2 * (C - A);
+                            nee_dir = normalize(light_pos - position);
+                            nee_face = (int32_t)gl.face;
+                            // distance at which this ray meets the emitter itself (same arithmetic as the
+                            // walk's triangle test); without such a hit the emitter cannot be the closest face
+                            f3 so = position + 1e-6f * normal;
+                            f3 e1 = B - A, e2 = C - A;
+                            f3 pvec = cross(nee_dir, e2);
+                            float det = dot(e1, pvec);
+                            float t_f = -1.0f;
+                            if (!(det > -PT_EPS_UP && det < PT_EPS_UP)) {
+                                float inv_det = 1.0f / det;
+                                f3 tvec = so - A;
+                                float uu = dot(tvec, pvec) * inv_det;
+                                if (!(uu <= -PT_EPS_UP || uu > 1.0f)) {
+                                    f3 qvec = cross(tvec, e1);
+                                    float vv = dot(nee_dir, qvec) * inv_det;
+                                    if (!(vv <= -PT_EPS_UP || (uu + vv) > 1.0f)) t_f = dot(e2, qvec) * inv_det;
                                 }
                             }
-                            if (skip_nee) {
-                                if (COUNT) n.rays++; // the reference still traced this shadow ray
-                                do_bsdf = true;
+                            if (t_f > 0) {
+                                s_init = t_f + t_f * kBand;
+                                s_stop = t_f - t_f * kBand;
+                                // sample_area_light, renderer.cu:131-133, with the emitter's baked normal and area
+                                float cos_theta_y = __builtin_fabsf(dot(ld3(gl.normal), nee_dir));
+                                float p_als = t_f * t_f / (gl.area * cos_theta_y);
+                                p_lss = p_lss * p_als;
                             } else {
-                                ro = position + 1e-6f * normal;
-                                rd = nee_dir;
-                                mode = kModeNee;
+                                can_see = false;
                             }
                         }
+                        if (can_see && p_lss > 0) {
+                            f3 l_ts = tbn_t_mul(vx, nee_dir);
+                            float p_brdf = brdf_pdf();
+                            f3 f_cos = brdf_eval(vx.brdf, vx.wo_ts, l_ts);
+                            f3 direct = f_cos * radiance;
+                            float weight = p_lss / (p_lss + p_brdf);
+                            direct_c = ((weight / p_lss) * thr) * direct;
+                            shadow = true;
+                        } else {
+                            if (COUNT) n.rays++; // the reference still traced this shadow ray
+                        }
+                    }
+
+                    // ---- BRDF::sample (brdf.cu:180-192) + next ray (renderer.cu:345-350) ----
+                    region_tick<COUNT>(n, kRegBsdf);
+                    f3 r;
+                    do {
+                        r.x = 2 * rng_uniform(rng) - 1;
+                        r.y = 2 * rng_uniform(rng) - 1;
+                        r.z = 2 * rng_uniform(rng) - 1;
+                    } while (dot(r, r) > 1);
+                    f3 wi = normalize(r);
+                    wi.z = __builtin_fabsf(wi.z);
+                    f_cos_next = brdf_eval(vx.brdf, vx.wo_ts, wi);
+                    if (COUNT) {
+                        n.bounces++;
+                        // the reference walks the BVH once per emissive LST node for the pdf
+                        n.rays += P.lst_face_nodes;
+                    }
+                    rd_next = tbn_mul(vx, wi);
+                    ro = position + 1e-6f * normal;
+                    if (shadow) {
+                        rd = nee_dir;
+                        mode = kModeNee;
+                        t_init = s_init;
+                        t_stop = s_stop;
+                    } else {
+                        rd = rd_next;
+                        pending = true;
                     }
                 }
             }
-        } else {
-            // ---- shadow walk finished: visibility + MIS-weighted direct light ----
-            region_tick<COUNT>(n, kRegNee);
-            if (COUNT) n.rays++;
-            float p_lss = nee_p;
-            if (nee_kind == 0) {
-                float closest = hit.face >= 0 ? hit.t : kNoHit;
-                if (hit.early || !(nee_dist < closest)) p_lss = 0;
-            } else if (nee_kind == 1) {
-                if (hit.face >= 0) p_lss = 0;
-            } else {
-                const GLight *gl = P.glights + nee_light;
-                bool visible = !hit.early && hit.face >= 0 && hit.t > 0 && hit.face == (int32_t)gl->face;
-                float p_als = 0.f;
-                if (visible) { // sample_area_light, renderer.cu:131-133, with the emitter's baked normal and area
-                    float cos_theta_y = __builtin_fabsf(dot(ld3(gl->normal), nee_dir));
-                    p_als = hit.t * hit.t / (gl->area * cos_theta_y);
-                }
-                p_lss = visible ? p_lss * p_als : 0.f;
-            }
-            if (p_lss > 0) {
-                f3 l_ts = tbn_t_mul(vx, nee_dir);
-                float p_brdf = brdf_pdf();
-                f3 f_cos = brdf_eval(vx.brdf, vx.wo_ts, l_ts);
-                f3 direct = f_cos * nee_radiance;
-                float weight = p_lss / (p_lss + p_brdf);
-                light = light + ((weight / p_lss) * thr) * direct;
-            }
-            do_bsdf = true;
         }
-
-        if (do_bsdf) {
-            region_tick<COUNT>(n, kRegBsdf);
-            // BRDF::sample (brdf.cu:180-192) + next ray (renderer.cu:345-350)
-            f3 r;
-            do {
-                r.x = 2 * rng_uniform(rng) - 1;
-                r.y = 2 * rng_uniform(rng) - 1;
-                r.z = 2 * rng_uniform(rng) - 1;
-            } while (dot(r, r) > 1);
-            f3 wi = normalize(r);
-            wi.z = __builtin_fabsf(wi.z);
-            f_cos_next = brdf_eval(vx.brdf, vx.wo_ts, wi);
-            if (COUNT) {
-                n.bounces++;
-                // the reference walks the BVH once per emissive LST node for the pdf
-                n.rays += P.lst_face_nodes;
-            }
-            rd = tbn_mul(vx, wi);
-            ro = vx.position + 1e-6f * vx.normal;
-            pending = true;
-            mode = kModeMain;
-            t_init = kNoHit;
-            t_stop = -1.0f;
-        }
-
-#if PT_SLICE > 0
         region_time<COUNT>(n, kRegMain, tsh0, stamp<COUNT>());
-#endif
         if (end_path) {
             total = total + light;
             sample++;
@@ -1094,6 +1092,8 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
             if (n.w_iters[k]) atomicAdd(&counters[8 + 2 * k], (unsigned long long)n.w_iters[k]);
             if (n.w_lanes[k]) atomicAdd(&counters[9 + 2 * k], (unsigned long long)n.w_lanes[k]);
         }
+        for (int k = 0; k < 3; k++)
+            if (n.w_idle[k]) atomicAdd(&counters[27 + k], (unsigned long long)n.w_idle[k]);
         if ((threadIdx.x & 63) == 0) { // lane 0 always reaches the end of the kernel
             for (int k = 0; k < 6; k++) atomicAdd(&counters[20 + k], n.w_time[k]);
             atomicAdd(&counters[26], stamp<COUNT>() - t_kernel0); // wave lifetime

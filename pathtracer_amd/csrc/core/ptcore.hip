@@ -596,6 +596,7 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
         out->region_ticks[k] = h[20 + k];
     }
     out->wave_ticks = h[26];
+    for (int k = 0; k < 3; k++) out->node_step_idle[k] = h[27 + k];
     out->samples = h[0];
     out->rays = h[1];
     out->inner_visits = h[2];

@@ -17,18 +17,29 @@ ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--spp", type=int, default=10)
 ap.add_argument("--batches", type=int, default=1)
 ap.add_argument("--count", action="store_true")
+ap.add_argument("--side", type=int, default=2236, help="grid scene: quads per side")
 a = ap.parse_args()
 
 gen = {"many_lights": scenes.write_many_lights_standin, "dragon": scenes.write_dragon_standin,
-       "cornell": scenes.write_cornell_like, "glass": scenes.write_glass_mirror_standin}[a.scene]
+       "cornell": scenes.write_cornell_like, "glass": scenes.write_glass_mirror_standin,
+       "grid": lambda d: scenes.write_synthetic_grid(d, side=a.side)}[a.scene]
+import time
+t_host = time.perf_counter()
 with tempfile.TemporaryDirectory() as d:
     kw = {}
     if a.scene == "glass":
         kw["clear_texture"] = scenes.write_sky_hdr(d + "/sky.hdr")
     scene = host.Scene.load_gltf(gen(d), **kw)
+t_load = time.perf_counter()
 bvh, lst = host.BVH(scene), host.LST(scene)
+t_bvh = time.perf_counter()
+print(f"host: write+load {t_load - t_host:.1f} s, BVH+LST {t_bvh - t_load:.1f} s; faces {len(scene.faces)}, "
+      f"bvh nodes {bvh.node_count}, stats {bvh.stats}, lst {len(lst.nodes)}", flush=True)
+if os.environ.get("PT_HOST_ONLY"):
+    sys.exit(0)
 r = core.Renderer(0)
 r.upload(scene, bvh, lst)
+print(f"upload {time.perf_counter() - t_bvh:.1f} s, device footprint {r.device_footprint() / 2**20:.0f} MiB", flush=True)
 r.configure(a.res, a.res, 0.0, (1.0, 1.0, 1.0) if a.scene == "glass" else (0.0, 0.0, 0.0))
 for b in range(a.batches):
     r.render_batch(42 + b, b * a.spp, a.spp)
@@ -41,7 +52,7 @@ if a.count:
     dt = time.perf_counter() - t0
     print(c)
     if "wave_ticks" in c:
-        # s_memtime ticks at 100 MHz (constant clock): wave-seconds resident / (slots * kernel time)
-        print(f"instrumented launch {dt*1e3:.1f} ms; wave-seconds {c['wave_ticks']/1e8:.2f}; "
-              f"mean resident waves {c['wave_ticks']/1e8/dt:.0f}")
+        # wave_ticks are shader-clock ticks summed over waves: / launch time = resident waves * clock
+        print(f"instrumented launch {dt*1e3:.1f} ms; resident waves x clock = {c['wave_ticks']/dt/1e9:.0f} G/s "
+              f"(3072 slots x ~2.4 GHz = 7373 when every slot is busy)")
 r.close()

@@ -685,32 +685,37 @@ PT_DEV uint32_t pixel_of_thread(const KernelParams &P, int *px, int *py) {
     return ty * ntx + tx;
 }
 
-// order[rank] = tile, rank = position of the tile when sorted by (cost descending, index ascending).
-// PT_LPT_MODE 2 ranks within the tile-row class ty % 8 (the XCD a tile ran on by default) and
-// interleaves the classes, so a tile keeps its XCD; mode 1 ranks globally.
-#ifndef PT_LPT_MODE
-#define PT_LPT_MODE 1
-#endif
-__global__ void __launch_bounds__(256) tile_rank_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order,
-                                                        uint32_t n, uint32_t ntx, uint32_t classes) {
+// Launch order for the next launch. key = (cost class, position in the static order): tiles are
+// ranked heaviest class first, and inside a class they keep the static XCD-interleaved order, so
+// neighbouring tiles still run together on one XCD (a plain sort by cost scatters them, which costs
+// more in L2 misses on a 10 M-triangle scene than the balance gains). Classes are quarter octaves
+// of the recorded ticks. order[rank(key)] = tile; keys are unique, so order is a permutation.
+__global__ void __launch_bounds__(256) tile_key_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ key,
+                                                       uint32_t n, uint32_t ntx, uint32_t nty) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    uint32_t c = cost[t] | 4u;
+    uint32_t msb = 31u - (uint32_t)__builtin_clz(c);
+    uint32_t cls = msb * 4u + ((c >> (msb - 2u)) & 3u); // <= 127
+    uint32_t tx = t % ntx, ty = t / ntx;
+    uint32_t w0 = (nty % 8u == 0) ? ((ty / 8u) * ntx + tx) * 8u + (ty % 8u) : t; // inverse of pixel_of_thread's static map
+    key[t] = ((127u - cls) << 24) | w0;
+}
+
+__global__ void __launch_bounds__(256) tile_rank_kernel(const uint32_t *__restrict__ key, uint32_t *__restrict__ order, uint32_t n) {
     __shared__ uint32_t chunk[256];
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t mine = i < n ? cost[i] : 0u;
-    uint32_t my_class = classes > 1 ? (i / ntx) % classes : 0u;
+    uint32_t mine = i < n ? key[i] : 0xFFFFFFFFu;
     uint32_t rank = 0;
     for (uint32_t base = 0; base < n; base += 256u) {
         uint32_t j = base + threadIdx.x;
-        chunk[threadIdx.x] = j < n ? cost[j] : 0u;
+        chunk[threadIdx.x] = j < n ? key[j] : 0xFFFFFFFFu;
         __syncthreads();
-        uint32_t m = n - base < 256u ? n - base : 256u;
-        for (uint32_t k = 0; k < m; k++) {
-            uint32_t c = chunk[k], jj = base + k;
-            bool same = classes > 1 ? ((jj / ntx) % classes == my_class) : true;
-            rank += (same && (c > mine || (c == mine && jj < i))) ? 1u : 0u;
-        }
+#pragma unroll 16
+        for (uint32_t k = 0; k < 256u; k++) rank += chunk[k] < mine ? 1u : 0u;
         __syncthreads();
     }
-    if (i < n) order[classes > 1 ? rank * classes + my_class : rank] = i;
+    if (i < n) order[rank] = i;
 }
 
 PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {

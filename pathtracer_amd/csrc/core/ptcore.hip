@@ -149,7 +149,7 @@ struct pt_context {
     DeviceArray<uint32_t> jump;
     DeviceArray<float> image;
     DeviceArray<unsigned long long> counters;
-    DeviceArray<uint32_t> tile_cost, tile_order; // one entry per 8x8 tile
+    DeviceArray<uint32_t> tile_cost, tile_key, tile_order; // one entry per 8x8 tile
     bool order_valid = false;                    // tile_order holds a permutation for this resolution
 
     bool have_scene = false, have_bvh = false, have_lst = false, have_cfg = false;
@@ -194,9 +194,10 @@ void launch_rank(pt_context *ctx, hipStream_t st) {
     if (!g_lpt) return;
     uint32_t ntx = ((uint32_t)ctx->P.width + 7u) / 8u, nty = ((uint32_t)ctx->P.height + 7u) / 8u;
     uint32_t n = ntx * nty;
-    uint32_t classes = (PT_LPT_MODE == 2 && nty % 8u == 0) ? 8u : 1u;
-    hipLaunchKernelGGL(tile_rank_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, ctx->tile_cost.ptr,
-                       ctx->tile_order.ptr, n, ntx, classes);
+    if (n >= (1u << 24)) return; // keys hold the static position in 24 bits; larger images keep the static order
+    dim3 grid((n + 255u) / 256u), block(256);
+    hipLaunchKernelGGL(tile_key_kernel, grid, block, 0, st, ctx->tile_cost.ptr, ctx->tile_key.ptr, n, ntx, nty);
+    hipLaunchKernelGGL(tile_rank_kernel, grid, block, 0, st, ctx->tile_key.ptr, ctx->tile_order.ptr, n);
     ctx->order_valid = true;
 }
 
@@ -262,6 +263,7 @@ extern "C" void pt_destroy(pt_context *ctx) {
     ctx->counters.release();
     ctx->tile_cost.release();
     ctx->tile_order.release();
+    ctx->tile_key.release();
     for (int i = 0; i < pt_context::kEventRing; i++) {
         if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
         if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
@@ -470,8 +472,10 @@ extern "C" int pt_configure(pt_context *ctx, const pt_render_config *cfg) {
     if (ctx->tile_cost.count != tiles) {
         ctx->tile_cost.release();
         ctx->tile_order.release();
-        ctx->tile_cost.count = ctx->tile_order.count = tiles;
+        ctx->tile_key.release();
+        ctx->tile_cost.count = ctx->tile_order.count = ctx->tile_key.count = tiles;
         HIP_TRY(hipMalloc((void **)&ctx->tile_cost.ptr, tiles * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&ctx->tile_key.ptr, tiles * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **)&ctx->tile_order.ptr, tiles * sizeof(uint32_t)));
         ctx->order_valid = false;
     }
@@ -611,5 +615,5 @@ extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
     if (!ctx) return 0;
     return ctx->nodes.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
            ctx->lst.bytes() + ctx->glights.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes() +
-           ctx->tile_cost.bytes() + ctx->tile_order.bytes();
+           ctx->tile_cost.bytes() + ctx->tile_key.bytes() + ctx->tile_order.bytes();
 }

@@ -141,6 +141,20 @@ def test_default_tangents_no_uv(renderer, scene_dir):
     _assert_images_match(renderer.read_image(), cpu)
 
 
+def test_sharded_render_single_rank(renderer, cornell_like):
+    """render.render_sharded (the torch-side accumulator + combine used for N GPUs) with one rank
+    must equal the library-owned accumulator path and the oracle, bit for bit."""
+    import torch
+    from pathtracer_amd import render
+    w, h = 72, 40
+    o = _setup(renderer, cornell_like, w, h)
+    img = render.render_sharded(renderer, w, h, 9, 10, 4)  # batches of 4, 4, 2
+    torch.cuda.synchronize()
+    gpu = img.cpu().numpy()
+    cpu = o.render(9, 10, 4)
+    _assert_images_match(gpu.reshape(cpu.shape), cpu)
+
+
 def test_counters_match_oracle(renderer, cornell_like):
     """Reference-equivalent ray count, samples, shaded hits and bounces are integers that must
     agree exactly; the kernel walks fewer trees than the reference traces rays."""

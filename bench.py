@@ -56,6 +56,23 @@ def cpu_baseline(scene, bvh, lst, threads):
             "mrays_per_s": round(ctr["rays"] / dt / 1e6, 3)}
 
 
+def pmc_traffic():
+    """Fabric/HBM bytes per launch of the render kernel from the newest committed PMC summary
+    (profiles/rNN_pmc_*.json: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE on this
+    workload, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950). Counters cannot be read
+    from inside this process, so the figure is the profiled one, not a live one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_*.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f)).get("derived", {})
+            if "hbm_traffic_per_launch" in d:
+                return int(d["hbm_traffic_per_launch"]), os.path.join("profiles", os.path.basename(f))
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +149,7 @@ def main():
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         abytes = algorithmic_bytes(counters, WIDTH, HEIGHT)
         achieved = abytes / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic()
         out = {
             "metric": "Msamples/s (node) many_lights 1024x1024x200spp", "value": round(samples / elapsed / 1e6, 3),
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -148,7 +166,7 @@ def main():
             "counters_per_step": counters,
             "image_finite": finite, "image_mean": round(mean, 6),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "render_kernel<false,32>", "algorithmic_bytes_per_launch": int(abytes)},
         }
         if not args.no_cpu_baseline:

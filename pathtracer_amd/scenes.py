@@ -53,12 +53,29 @@ class GltfWriter:
         self.doc["accessors"].append(acc)
         return len(self.doc["accessors"]) - 1
 
+    def texture(self, uri, wrap_s=10497, wrap_t=10497, mag_filter=9729):
+        """Image file (relative uri) + its own sampler; returns the texture index."""
+        self.doc.setdefault("images", []).append({"uri": uri})
+        self.doc.setdefault("samplers", []).append({"magFilter": mag_filter, "minFilter": 9987, "wrapS": wrap_s, "wrapT": wrap_t})
+        self.doc.setdefault("textures", []).append({"source": len(self.doc["images"]) - 1,
+                                                    "sampler": len(self.doc["samplers"]) - 1})
+        return len(self.doc["textures"]) - 1
+
     def material(self, name, base_color, metallic=0.0, roughness=0.5, emissive=None, emissive_strength=None,
-                 extensions=None, omit_metallic=False):
+                 extensions=None, omit_metallic=False, base_color_texture=None, metallic_roughness_texture=None,
+                 alpha_mode=None, alpha_cutoff=None):
         pbr = {"baseColorFactor": [float(c) for c in base_color], "roughnessFactor": float(roughness)}
         if not omit_metallic:
             pbr["metallicFactor"] = float(metallic)
+        if base_color_texture is not None:
+            pbr["baseColorTexture"] = {"index": base_color_texture}
+        if metallic_roughness_texture is not None:
+            pbr["metallicRoughnessTexture"] = {"index": metallic_roughness_texture}
         m = {"doubleSided": True, "name": name, "pbrMetallicRoughness": pbr}
+        if alpha_mode is not None:
+            m["alphaMode"] = alpha_mode
+        if alpha_cutoff is not None:
+            m["alphaCutoff"] = float(alpha_cutoff)
         ext = dict(extensions or {})
         if emissive is not None:
             m["emissiveFactor"] = [float(c) for c in emissive]
@@ -292,6 +309,69 @@ def write_glass_mirror_standin(directory, name="glass_mirror_standin", detail=24
     m2 = w.mesh("Sphere.001", [w.primitive(p, n, idx, glass, uv)])
     w.node("Sphere.001", mesh=m2, scale=(0.30951082706451416,) * 3,
            translation=(0.24995926022529602, -0.2790658473968506, -0.6951195001602173))
+    return w.write(directory, name)
+
+
+def write_png_rgba8(path, img):
+    """Plain RGBA8 PNG (filter 0, one zlib stream) from an (H, W, 4) uint8 array."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, _ = img.shape
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    return path
+
+
+def write_textured_standin(directory, name="textured_standin", detail=20):
+    """Room whose objects exercise the material texture path (scene.cu:388-470, intersect.cu:137-160):
+    a checker base-colour texture with an alpha channel on a MASK material, a metallic-roughness
+    texture, a BLEND quad whose alpha drives the stochastic pass-through (renderer.cu:310-314), and
+    the three wrap modes / both filters (uvs run outside [0,1])."""
+    os.makedirs(directory, exist_ok=True)
+    rng = np.random.RandomState(3)
+    n = 32
+    yy, xx = np.mgrid[0:n, 0:n]
+    checker = (((xx // 4) + (yy // 4)) % 2).astype(np.uint8)
+    base = np.zeros((n, n, 4), np.uint8)
+    base[..., 0] = 60 + 180 * checker
+    base[..., 1] = 200 - 120 * checker
+    base[..., 2] = rng.randint(40, 255, (n, n))
+    base[..., 3] = np.where((xx + yy) % 7 == 0, 40, 255)  # holes for the MASK cutoff
+    write_png_rgba8(os.path.join(directory, name + "_base.png"), base)
+    mr = np.zeros((n, n, 4), np.uint8)
+    mr[..., 1] = rng.randint(30, 255, (n, n))   # roughness (G)
+    mr[..., 2] = 255 * checker                  # metallic (B)
+    mr[..., 3] = 255
+    write_png_rgba8(os.path.join(directory, name + "_mr.png"), mr)
+    veil = np.zeros((8, 8, 4), np.uint8)
+    veil[..., :3] = 230
+    veil[..., 3] = np.linspace(30, 220, 64).reshape(8, 8).astype(np.uint8)
+    write_png_rgba8(os.path.join(directory, name + "_veil.png"), veil)
+
+    w = GltfWriter()
+    _room(w, 4)
+    emit = w.material("EMIT", (0, 0, 0, 1), emissive=(1, 1, 1), emissive_strength=4)
+    t_base = w.texture(name + "_base.png", wrap_s=33648, wrap_t=10497, mag_filter=9729)   # mirrored / repeat, linear
+    t_mr = w.texture(name + "_mr.png", wrap_s=33071, wrap_t=33071, mag_filter=9728)       # clamp, nearest
+    t_veil = w.texture(name + "_veil.png")
+    cut = w.material("CUTOUT", (1, 1, 1, 1), roughness=1.0, metallic=1.0, base_color_texture=t_base,
+                     metallic_roughness_texture=t_mr, alpha_mode="MASK", alpha_cutoff=0.5)
+    veil_m = w.material("VEIL", (0.9, 0.9, 1.0, 0.8), roughness=0.4, base_color_texture=t_veil, alpha_mode="BLEND")
+    w.node("Plane.001", mesh=w.mesh("Plane.001", [unit_plane(w, emit)]), rotation=(-1, 0, 0, 1.6292069915380125e-07),
+           scale=(0.345,) * 3, translation=(0.0116, 8.3e-05, 0.9759))
+    p, nrm, uv, idx = blob(detail, 2 * detail, bump=0.2, seed=5)
+    w.node("Cutout", mesh=w.mesh("Cutout", [w.primitive(p, nrm, idx, cut, uv * 2.5 - 0.6)]), scale=(0.45,) * 3,
+           translation=(-0.2, 0.1, -0.45))
+    pos, qn, quv, qi = quad((0.6, -0.7, -0.9), (0.6, 0.7, -0.9), (0.6, -0.7, 0.5), (0.6, 0.7, 0.5), (1, 0, 0))
+    w.node("Veil", mesh=w.mesh("Veil", [w.primitive(pos, qn, qi, veil_m, quv)]))
+    w.node("Light", light=w.light("point", 40.0), translation=(0.8, -0.5, 0.6))
     return w.write(directory, name)
 
 

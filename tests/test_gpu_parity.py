@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import binding as ob
-from pathtracer_amd import core, host, scenes
+from pathtracer_amd import _ffi, core, host, scenes
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -153,6 +153,83 @@ def test_sharded_render_single_rank(renderer, cornell_like):
     gpu = img.cpu().numpy()
     cpu = o.render(9, 10, 4)
     _assert_images_match(gpu.reshape(cpu.shape), cpu)
+
+
+def test_material_textures_and_alpha_modes(renderer, scene_dir):
+    """Base-colour + metallic-roughness textures (mirrored / repeat / clamp wrap, linear and
+    nearest filter, uvs outside [0,1]), MASK cutoff and BLEND stochastic pass-through."""
+    b = util.load_bundle(scenes.write_textured_standin(scene_dir))
+    m = b.scene.materials
+    assert (m["baseColorTexture"] >= 0).sum() == 2 and (m["metallicRoughnessTexture"] >= 0).sum() == 1
+    o = _setup(renderer, b, 96, 80)
+    renderer.clear()
+    renderer.render_batch(11, 0, 6)
+    cpu, c = o.render_batch(11, 0, 6)
+    _assert_images_match(renderer.read_image(), cpu)
+    g = renderer.count_batch(11, 6)
+    assert g["rays"] == c["rays"] and g["shaded_hits"] == c["shaded_hits"]
+
+
+class _ArraysBvh:
+    def __init__(self, nodes, indices):
+        self.nodes, self.indices = nodes, indices
+
+
+def _chain_bvh(scene):
+    """Degenerate but valid tree: node k = (leaf of face k, node k+1). Height = face count."""
+    v, f = scene.vertices, scene.faces
+    tri = v["position"][f["vertices"]]                      # (F, 3, 3)
+    lo, hi = tri.min(axis=1), tri.max(axis=1)
+    F = len(f)
+    nodes = np.zeros(2 * F - 1, _ffi.BVH_NODE_DTYPE)
+    suffix_lo, suffix_hi = lo.copy(), hi.copy()
+    for k in range(F - 2, -1, -1):
+        suffix_lo[k] = np.minimum(lo[k], suffix_lo[k + 1])
+        suffix_hi[k] = np.maximum(hi[k], suffix_hi[k + 1])
+    for k in range(F - 1):
+        inner, leaf = 2 * k, 2 * k + 1
+        nodes[inner]["bmin"], nodes[inner]["bmax"] = suffix_lo[k], suffix_hi[k]
+        nodes[inner]["leftChild"] = leaf
+        nodes[inner]["rightChild"] = 2 * k + 2
+        nodes[leaf]["bmin"], nodes[leaf]["bmax"] = lo[k], hi[k]
+        nodes[leaf]["start"], nodes[leaf]["end"] = k, k + 1
+    last = 2 * F - 2
+    nodes[last]["bmin"], nodes[last]["bmax"] = lo[F - 1], hi[F - 1]
+    nodes[last]["start"], nodes[last]["end"] = F - 1, F
+    return _ArraysBvh(nodes, np.arange(F, dtype=np.uint32))
+
+
+def test_tall_tree_uses_the_64_entry_stack(renderer, scene_dir):
+    """A 50-level chain handed over in the reference's node format: the upload picks the 64-entry
+    stack instantiation (bvh.cu:338-342 allows 64), and caller-built trees are honoured as given."""
+    b = util.load_bundle(scenes.write_cornell_like(scene_dir, name="tiny_room", detail=2))
+    assert 34 < len(b.scene.faces) <= 64
+    b.bvh = _chain_bvh(b.scene)
+    o = _setup(renderer, b, 48, 40)
+    renderer.clear()
+    renderer.render_batch(2, 0, 5)
+    cpu, _ = o.render_batch(2, 0, 5)
+    _assert_images_match(renderer.read_image(), cpu)
+    gi, gd = renderer.primary_hits(2, True)
+    ci, cd = o.primary_hits(2, True)
+    assert int((gi != ci).sum()) == 0 and np.array_equal(util.bits(gd), util.bits(cd))
+
+
+def test_single_leaf_tree_and_one_sample(renderer, scene_dir):
+    """Two triangles: the root is a leaf (bvh.cu:143); one sample per launch, 3 launches."""
+    w = scenes.GltfWriter()
+    w.doc.setdefault("extensionsUsed", []).append("KHR_materials_emissive_strength")
+    emit = w.material("EMIT", (0.2, 0.2, 0.2, 1), emissive=(1, 0.5, 0.25), emissive_strength=2)
+    w.node("Plane", mesh=w.mesh("Plane", [scenes.unit_plane(w, emit)]), rotation=(0, 0.7071068, 0, 0.7071068))
+    w.node("Camera", camera=w.camera(scenes.ROOM_CAMERA["yfov"]), rotation=scenes.ROOM_CAMERA["rotation"],
+           translation=scenes.ROOM_CAMERA["translation"])
+    b = util.load_bundle(w.write(scene_dir, "two_tris"))
+    assert len(b.scene.faces) == 2 and len(b.bvh.nodes) == 1
+    o = _setup(renderer, b, 40, 24, clear=(0.1, 0.2, 0.3))
+    gpu = renderer.render(3, 3, 1)
+    cpu = o.render(3, 3, 1)
+    _assert_images_match(gpu, cpu)
+    assert gpu.max() > 0.3  # the emitter is in view
 
 
 def test_counters_match_oracle(renderer, cornell_like):

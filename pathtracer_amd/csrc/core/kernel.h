@@ -726,6 +726,284 @@ PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {
     *d = normalize(a);
 }
 
+// ---- one pixel's path state between walks --------------------------------------------------
+
+struct Path {
+    Rng rng;
+    f3 light, thr;
+    f3 ro, rd;         // the ray to walk next
+    float t_init, t_stop; // its limits (see kBand); t_stop == -1 for a main ray
+    int mode;          // kModeMain | kModeNee: what that ray is
+    float rr_prob;
+    f3 f_cos_next;     // BSDF sample's f*cos, applied once p_direct is known
+    bool pending;      // a BSDF sample is waiting for the next hit to finish its MIS weight
+    // Carried across a shadow walk. Every random draw of a path vertex (light choice, point on the
+    // emitter, BSDF direction) precedes both of its rays in the reference (renderer.cu:330-351), and
+    // the distance at which a visible emitter is met is known beforehand (t_f below), so the vertex
+    // handler finishes ALL of the vertex's arithmetic: the MIS-weighted direct term as it would be
+    // if the light is visible (direct_c) and the next bounce ray (rd_next). The shadow walk only
+    // answers "visible?", and its result needs no second heavy handler.
+    f3 rd_next, direct_c;
+    float nee_dist;
+    int nee_kind;      // 0 point, 1 directional, 2 area
+    int32_t nee_face;
+};
+
+// First ray of a sample (render_kernel's loop body up to integrate_Li, renderer.cu:376-388).
+template <bool COUNT>
+PT_DEV void start_sample(const KernelParams &P, int px, int py, Path &s, Tally &n) {
+    float sx = (float)px + 0.33f * rng_normal(s.rng);
+    float sy = (float)py + 0.33f * rng_normal(s.rng);
+    float u = (2 * sx - (float)P.width) / (float)P.height;
+    float v = (2 * sy - (float)P.height) / (float)P.height;
+    camera_ray(P, u, v, &s.ro, &s.rd);
+    s.light = mk3(0, 0, 0);
+    s.thr = mk3(1, 1, 1);
+    s.pending = false;
+    s.mode = kModeMain;
+    s.t_init = kNoHit;
+    s.t_stop = -1.0f;
+    if (COUNT) n.samples++;
+}
+
+// Shadow walk finished: visibility only (sample_light_source, renderer.cu:193-247); the next
+// bounce ray leaves from the same origin (renderer.cu:203, :350).
+template <bool COUNT>
+PT_DEV void shadow_result(const HitLite &h, Path &s, Tally &n) {
+    if (COUNT) n.rays++;
+    bool visible;
+    if (s.nee_kind == 0) {
+        float closest = h.face >= 0 ? h.t : kNoHit;
+        visible = !h.early && s.nee_dist < closest;
+    } else if (s.nee_kind == 1) {
+        visible = h.face < 0;
+    } else { // met the emitter itself, in front of the origin, nothing nearer (then h.t == t_f)
+        visible = !h.early && h.face == s.nee_face && h.t > 0;
+    }
+    if (visible) s.light = s.light + s.direct_c;
+    s.rd = s.rd_next;
+    s.pending = true;
+    s.mode = kModeMain;
+    s.t_init = kNoHit;
+    s.t_stop = -1.0f;
+}
+
+// Main-ray result: one handler per path vertex. Returns true when the path ended (the caller adds
+// s.light to the pixel and starts the next sample); otherwise s holds the next ray.
+template <bool COUNT>
+PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n) {
+    // ---- main-ray result: one handler per path vertex ----
+    region_tick<COUNT>(n, kRegMain);
+    if (COUNT) n.rays++;
+    bool end_path = false;
+    const bool sh = hit.face >= 0;
+    GShade gs;
+    GMaterial m;
+    if (sh) { // both records are addressed by the walk's result, so the two fetches overlap
+        gs = P.shade[hit.face];
+        m = P.materials[hit.material];
+    }
+    if (s.pending) {
+        // evaluate_direct_p: only the LST node whose face this ray hit contributes
+        float p_direct = 0.f;
+        if (P.lst_count != 0) {
+            if (sh && (gs.flags & kShadeIsLight) && hit.t > 0) {
+                // a face listed k times in the LST contributes k equal terms
+                float p_als = area_pdf(&gs, s.rd, hit.t, nullptr);
+                for (uint32_t k = gs.flags >> 8; k > 0; k--) p_direct += p_als;
+            }
+            p_direct = p_direct / (float)P.lst_count;
+        }
+        float pdf = brdf_pdf();
+        float weight = pdf / (p_direct + pdf);
+        s.thr = s.thr * (s.f_cos_next * (weight / (pdf * s.rr_prob)));
+        s.pending = false;
+    }
+    if (!sh) {
+        f3 clear = ld3(P.clear_color);
+        if (P.clear_texture >= 0) {
+            float phi = pt_atan2f(s.rd.z, s.rd.x);
+            float theta = pt_acosf(min_gl(max_gl(s.rd.y, -1.0f), 1.0f));
+            float eu = (float)(((double)phi + PT_PI_D) / (2.0f * PT_PI_D));
+            float ev = (float)((double)theta / PT_PI_D);
+            float4 t = sample_texture(P.textures + P.clear_texture, eu, ev);
+            clear = clear * mk3(t.x, t.y, t.z);
+        }
+        s.light = s.light + s.thr * clear;
+        end_path = true;
+    } else {
+        // ---- hit record (intersect.cu:100-198) ----
+        float u = hit.u, v = hit.v;
+        float w = (float)(1.0 - (double)u - (double)v);
+        f3 position = (w * ld3(gs.pos[0]) + u * ld3(gs.pos[1])) + v * ld3(gs.pos[2]);
+        f3 baseColor = mk3(m.baseColorFactor[0], m.baseColorFactor[1], m.baseColorFactor[2]);
+        float alpha = m.baseColorFactor[3];
+        float roughness = m.roughness, metallic = m.metallic;
+        if (m.baseColorTexture >= 0 || m.metallicRoughnessTexture >= 0) {
+            float tu = (w * gs.uv[0][0] + u * gs.uv[1][0]) + v * gs.uv[2][0];
+            float tv = (w * gs.uv[0][1] + u * gs.uv[1][1]) + v * gs.uv[2][1];
+            if (m.baseColorTexture >= 0) {
+                float4 t = sample_texture(P.textures + m.baseColorTexture, tu, tv);
+                baseColor = baseColor * mk3(t.x, t.y, t.z);
+                alpha *= t.w;
+            }
+            if (m.metallicRoughnessTexture >= 0) {
+                float4 t = sample_texture(P.textures + m.metallicRoughnessTexture, tu, tv);
+                roughness *= t.y;
+                metallic *= t.z;
+            }
+        }
+        if (m.alphaMode == PT_ALPHA_OPAQUE) alpha = 1.0f;
+        else if (m.alphaMode == PT_ALPHA_MASK) alpha = alpha > m.alphaCutoff ? 1.0f : 0.0f;
+
+        f3 normal, tangent;
+        if (gs.flags & kShadeFlat) {
+            normal = ld3(gs.nrm[0]);
+            tangent = ld3(gs.tan[0]);
+        } else {
+            normal = (w * ld3(gs.nrm[0]) + u * ld3(gs.nrm[1])) + v * ld3(gs.nrm[2]);
+            tangent = (w * ld3(gs.tan[0]) + u * ld3(gs.tan[1])) + v * ld3(gs.tan[2]);
+        }
+        float handed = gs.handed < 0 ? -1.0f : 1.0f;
+        f3 bitangent = handed * cross(normal, tangent);
+        tangent = normalize(tangent);
+        bitangent = normalize(bitangent);
+        normal = normalize(normal);
+        if (dot(normal, s.rd) > 0) {
+            tangent = tangent * -1.0f;
+            bitangent = bitangent * -1.0f;
+            normal = normal * -1.0f;
+        }
+
+        // ---- integrate_Li body (renderer.cu:309-355) ----
+        if (rng_uniform(s.rng) >= alpha) {
+            s.ro = position + 1e-6f * (-normal);
+            // direction unchanged; no RR, no throughput change (renderer.cu:310-314)
+        } else {
+            if (COUNT) n.shaded++;
+            s.light = s.light + ld3(m.emissive) * s.thr;
+            s.rr_prob = min_gl(luminance(s.thr), 0.99f);
+            if (rng_uniform(s.rng) >= s.rr_prob) {
+                end_path = true;
+            } else {
+                Vertex vx;
+                vx.position = position;
+                vx.normal = normal;
+                vx.tx = tangent;
+                vx.ty = bitangent;
+                vx.brdf.baseColor = baseColor;
+                vx.brdf.roughness = roughness;
+                vx.brdf.metallic = metallic;
+                vx.brdf.specular = m.specular;
+                vx.wo_ts = tbn_t_mul(vx, -s.rd);
+
+                // ---- sample_light_source (renderer.cu:164-249), everything but the visibility walk ----
+                bool shadow = false;
+                f3 nee_dir = mk3(0, 0, 0);
+                float s_init = kNoHit, s_stop = -1.0f;
+                if (P.lst_count != 0) {
+                    int node_index = (int)((float)P.lst_count * rng_uniform(s.rng));
+                    GLight gl = P.glights[(uint32_t)node_index % P.lst_count];
+                    float p_lss = 1.0f / (float)P.lst_count; // times the area pdf for an emitter
+                    f3 radiance = ld3(gl.radiance);
+                    f3 A = ld3(gl.a), B = ld3(gl.b), C = ld3(gl.c);
+                    bool can_see = true; // false: the reference's walk cannot end on this s.light
+                    s.nee_kind = (int)gl.kind;
+                    if (gl.kind == 0) {
+                        f3 dl = A - position;
+                        float distance = length(dl);
+                        nee_dir = dl / distance;
+                        s.nee_dist = distance;
+                        radiance = radiance / (distance * distance);
+                        s_init = distance + distance * kBand;
+                        s_stop = distance - distance * kBand;
+                    } else if (gl.kind == 1) {
+                        nee_dir = A;
+                        s_init = kNoHit; // visible iff nothing at all is hit: stop at the first hit
+                        s_stop = kNoHit;
+                    } else {
+                        float u1, u2;
+                        do {
+                            u1 = rng_uniform(s.rng);
+                            u2 = rng_uniform(s.rng);
+                        } while (u1 + u2 > 1);
+                        f3 light_pos = (A + u1 * (B - A)) + u2 * (C - A);
+                        nee_dir = normalize(light_pos - position);
+                        s.nee_face = (int32_t)gl.face;
+                        // distance at which this ray meets the emitter itself (same arithmetic as the
+                        // walk's triangle test); without such a hit the emitter cannot be the closest face
+                        f3 so = position + 1e-6f * normal;
+                        f3 e1 = B - A, e2 = C - A;
+                        f3 pvec = cross(nee_dir, e2);
+                        float det = dot(e1, pvec);
+                        float t_f = -1.0f;
+                        if (!(det > -PT_EPS_UP && det < PT_EPS_UP)) {
+                            float inv_det = 1.0f / det;
+                            f3 tvec = so - A;
+                            float uu = dot(tvec, pvec) * inv_det;
+                            if (!(uu <= -PT_EPS_UP || uu > 1.0f)) {
+                                f3 qvec = cross(tvec, e1);
+                                float vv = dot(nee_dir, qvec) * inv_det;
+                                if (!(vv <= -PT_EPS_UP || (uu + vv) > 1.0f)) t_f = dot(e2, qvec) * inv_det;
+                            }
+                        }
+                        if (t_f > 0) {
+                            s_init = t_f + t_f * kBand;
+                            s_stop = t_f - t_f * kBand;
+                            // sample_area_light, renderer.cu:131-133, with the emitter's baked normal and area
+                            float cos_theta_y = __builtin_fabsf(dot(ld3(gl.normal), nee_dir));
+                            float p_als = t_f * t_f / (gl.area * cos_theta_y);
+                            p_lss = p_lss * p_als;
+                        } else {
+                            can_see = false;
+                        }
+                    }
+                    if (can_see && p_lss > 0) {
+                        f3 l_ts = tbn_t_mul(vx, nee_dir);
+                        float p_brdf = brdf_pdf();
+                        f3 f_cos = brdf_eval(vx.brdf, vx.wo_ts, l_ts);
+                        f3 direct = f_cos * radiance;
+                        float weight = p_lss / (p_lss + p_brdf);
+                        s.direct_c = ((weight / p_lss) * s.thr) * direct;
+                        shadow = true;
+                    } else {
+                        if (COUNT) n.rays++; // the reference still traced this shadow ray
+                    }
+                }
+
+                // ---- BRDF::sample (brdf.cu:180-192) + next ray (renderer.cu:345-350) ----
+                region_tick<COUNT>(n, kRegBsdf);
+                f3 r;
+                do {
+                    r.x = 2 * rng_uniform(s.rng) - 1;
+                    r.y = 2 * rng_uniform(s.rng) - 1;
+                    r.z = 2 * rng_uniform(s.rng) - 1;
+                } while (dot(r, r) > 1);
+                f3 wi = normalize(r);
+                wi.z = __builtin_fabsf(wi.z);
+                s.f_cos_next = brdf_eval(vx.brdf, vx.wo_ts, wi);
+                if (COUNT) {
+                    n.bounces++;
+                    // the reference walks the BVH once per emissive LST node for the pdf
+                    n.rays += P.lst_face_nodes;
+                }
+                s.rd_next = tbn_mul(vx, wi);
+                s.ro = position + 1e-6f * normal;
+                if (shadow) {
+                    s.rd = nee_dir;
+                    s.mode = kModeNee;
+                    s.t_init = s_init;
+                    s.t_stop = s_stop;
+                } else {
+                    s.rd = s.rd_next;
+                    s.pending = true;
+                }
+            }
+        }
+    }
+    return end_path;
+}
+
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 3
 #endif
@@ -746,48 +1024,27 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
     }
     unsigned long long t_kernel0 = stamp<COUNT>();
 
-    Rng rng;
-    rng_init(rng, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(py * P.width + px) : 0u);
+    Path s = {};
+    rng_init(s.rng, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(py * P.width + px) : 0u);
 
     f3 total = mk3(0, 0, 0);
-    f3 light = mk3(0, 0, 0), thr = mk3(1, 1, 1);
-    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
-    float rr_prob = 1.f;
-    f3 f_cos_next = mk3(0, 0, 0); // BSDF sample's f*cos, applied once p_direct is known
-    bool pending = false;         // a BSDF sample is waiting for the next hit to finish its MIS weight
-    // Carried across a shadow walk. Every random draw of a path vertex (light choice, point on the
-    // emitter, BSDF direction) precedes both of its rays in the reference (renderer.cu:330-351), and
-    // the distance at which a visible emitter is met is known beforehand (t_f below), so the vertex
-    // handler finishes ALL of the vertex's arithmetic: the MIS-weighted direct term as it would be
-    // if the light is visible (direct_c) and the next bounce ray (rd_next). The shadow walk only
-    // answers "visible?", and its result needs no second heavy handler.
-    f3 rd_next = mk3(0, 0, 1), direct_c = mk3(0, 0, 0);
-    float nee_dist = 0.f;
-    int nee_kind = 0; // 0 point, 1 directional, 2 area
-    int32_t nee_face = -1;
-    float t_init = kNoHit, t_stop = -1.0f; // limits of the next walk (see kBand)
+    s.thr = mk3(1, 1, 1);
+    s.rd = s.rd_next = mk3(0, 0, 1);
+    s.rr_prob = 1.f;
+    s.nee_face = -1;
+    s.t_init = kNoHit;
+    s.t_stop = -1.0f;
+    s.mode = kModeMain;
     Walk wk = {};
     bool walking = false;
-    int mode = kModeMain;
     int sample = 0;
     bool need_camera = true;
     bool alive = inside && P.current_samples > 0;
 
     while (alive) {
         if (need_camera) {
-            float sx = (float)px + 0.33f * rng_normal(rng);
-            float sy = (float)py + 0.33f * rng_normal(rng);
-            float u = (2 * sx - (float)P.width) / (float)P.height;
-            float v = (2 * sy - (float)P.height) / (float)P.height;
-            camera_ray(P, u, v, &ro, &rd);
-            light = mk3(0, 0, 0);
-            thr = mk3(1, 1, 1);
-            pending = false;
-            mode = kModeMain;
-            t_init = kNoHit;
-            t_stop = -1.0f;
+            start_sample<COUNT>(P, px, py, s, n);
             need_camera = false;
-            if (COUNT) n.samples++;
         }
 
         region_tick<COUNT>(n, kRegLoop);
@@ -796,7 +1053,7 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
             wk.ref = P.root;
             wk.pleaf = 0;
             wk.sp = 0;
-            wk.h.t = t_init;
+            wk.h.t = s.t_init;
             wk.h.u = wk.h.v = 0.f;
             wk.h.face = -1;
             wk.h.material = 0;
@@ -808,30 +1065,14 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
             if (COUNT) n.walks++;
             walking = true;
         }
-        walk_slice<COUNT, STACK>(P, ro, rd, t_stop, stack, wk, n);
+        walk_slice<COUNT, STACK>(P, s.ro, s.rd, s.t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
         const bool finished = wk.ref == kDone && wk.pleaf == 0;
 
-        if (finished && mode == kModeNee) {
+        if (finished && s.mode == kModeNee) { // shadow results are handled on the spot
             unsigned long long tn0 = stamp<COUNT>();
-            // ---- shadow walk finished: visibility only (sample_light_source, renderer.cu:193-247) ----
             region_tick<COUNT>(n, kRegNee);
-            if (COUNT) n.rays++;
-            bool visible;
-            if (nee_kind == 0) {
-                float closest = wk.h.face >= 0 ? wk.h.t : kNoHit;
-                visible = !wk.h.early && nee_dist < closest;
-            } else if (nee_kind == 1) {
-                visible = wk.h.face < 0;
-            } else { // met the emitter itself, in front of the origin, nothing nearer (then wk.h.t == t_f)
-                visible = !wk.h.early && wk.h.face == nee_face && wk.h.t > 0;
-            }
-            if (visible) light = light + direct_c;
-            rd = rd_next; // same origin (renderer.cu:203, :350)
-            pending = true;
-            mode = kModeMain;
-            t_init = kNoHit;
-            t_stop = -1.0f;
+            shadow_result<COUNT>(wk.h, s, n);
             walking = false;
             region_time<COUNT>(n, kRegNee, tn0, stamp<COUNT>());
             continue;
@@ -850,217 +1091,10 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
         if (hit.face < 0) hit.t = kNoHit;
 
         // ---- main-ray result: one handler per path vertex ----
-        region_tick<COUNT>(n, kRegMain);
-        if (COUNT) n.rays++;
-        bool end_path = false;
-        const bool sh = hit.face >= 0;
-        GShade s;
-        GMaterial m;
-        if (sh) { // both records are addressed by the walk's result, so the two fetches overlap
-            s = P.shade[hit.face];
-            m = P.materials[hit.material];
-        }
-        if (pending) {
-            // evaluate_direct_p: only the LST node whose face this ray hit contributes
-            float p_direct = 0.f;
-            if (P.lst_count != 0) {
-                if (sh && (s.flags & kShadeIsLight) && hit.t > 0) {
-                    // a face listed k times in the LST contributes k equal terms
-                    float p_als = area_pdf(&s, rd, hit.t, nullptr);
-                    for (uint32_t k = s.flags >> 8; k > 0; k--) p_direct += p_als;
-                }
-                p_direct = p_direct / (float)P.lst_count;
-            }
-            float pdf = brdf_pdf();
-            float weight = pdf / (p_direct + pdf);
-            thr = thr * (f_cos_next * (weight / (pdf * rr_prob)));
-            pending = false;
-        }
-        if (!sh) {
-            f3 clear = ld3(P.clear_color);
-            if (P.clear_texture >= 0) {
-                float phi = pt_atan2f(rd.z, rd.x);
-                float theta = pt_acosf(min_gl(max_gl(rd.y, -1.0f), 1.0f));
-                float eu = (float)(((double)phi + PT_PI_D) / (2.0f * PT_PI_D));
-                float ev = (float)((double)theta / PT_PI_D);
-                float4 t = sample_texture(P.textures + P.clear_texture, eu, ev);
-                clear = clear * mk3(t.x, t.y, t.z);
-            }
-            light = light + thr * clear;
-            end_path = true;
-        } else {
-            // ---- hit record (intersect.cu:100-198) ----
-            float u = hit.u, v = hit.v;
-            float w = (float)(1.0 - (double)u - (double)v);
-            f3 position = (w * ld3(s.pos[0]) + u * ld3(s.pos[1])) + v * ld3(s.pos[2]);
-            f3 baseColor = mk3(m.baseColorFactor[0], m.baseColorFactor[1], m.baseColorFactor[2]);
-            float alpha = m.baseColorFactor[3];
-            float roughness = m.roughness, metallic = m.metallic;
-            if (m.baseColorTexture >= 0 || m.metallicRoughnessTexture >= 0) {
-                float tu = (w * s.uv[0][0] + u * s.uv[1][0]) + v * s.uv[2][0];
-                float tv = (w * s.uv[0][1] + u * s.uv[1][1]) + v * s.uv[2][1];
-                if (m.baseColorTexture >= 0) {
-                    float4 t = sample_texture(P.textures + m.baseColorTexture, tu, tv);
-                    baseColor = baseColor * mk3(t.x, t.y, t.z);
-                    alpha *= t.w;
-                }
-                if (m.metallicRoughnessTexture >= 0) {
-                    float4 t = sample_texture(P.textures + m.metallicRoughnessTexture, tu, tv);
-                    roughness *= t.y;
-                    metallic *= t.z;
-                }
-            }
-            if (m.alphaMode == PT_ALPHA_OPAQUE) alpha = 1.0f;
-            else if (m.alphaMode == PT_ALPHA_MASK) alpha = alpha > m.alphaCutoff ? 1.0f : 0.0f;
-
-            f3 normal, tangent;
-            if (s.flags & kShadeFlat) {
-                normal = ld3(s.nrm[0]);
-                tangent = ld3(s.tan[0]);
-            } else {
-                normal = (w * ld3(s.nrm[0]) + u * ld3(s.nrm[1])) + v * ld3(s.nrm[2]);
-                tangent = (w * ld3(s.tan[0]) + u * ld3(s.tan[1])) + v * ld3(s.tan[2]);
-            }
-            float handed = s.handed < 0 ? -1.0f : 1.0f;
-            f3 bitangent = handed * cross(normal, tangent);
-            tangent = normalize(tangent);
-            bitangent = normalize(bitangent);
-            normal = normalize(normal);
-            if (dot(normal, rd) > 0) {
-                tangent = tangent * -1.0f;
-                bitangent = bitangent * -1.0f;
-                normal = normal * -1.0f;
-            }
-
-            // ---- integrate_Li body (renderer.cu:309-355) ----
-            if (rng_uniform(rng) >= alpha) {
-                ro = position + 1e-6f * (-normal);
-                // direction unchanged; no RR, no throughput change (renderer.cu:310-314)
-            } else {
-                if (COUNT) n.shaded++;
-                light = light + ld3(m.emissive) * thr;
-                rr_prob = min_gl(luminance(thr), 0.99f);
-                if (rng_uniform(rng) >= rr_prob) {
-                    end_path = true;
-                } else {
-                    Vertex vx;
-                    vx.position = position;
-                    vx.normal = normal;
-                    vx.tx = tangent;
-                    vx.ty = bitangent;
-                    vx.brdf.baseColor = baseColor;
-                    vx.brdf.roughness = roughness;
-                    vx.brdf.metallic = metallic;
-                    vx.brdf.specular = m.specular;
-                    vx.wo_ts = tbn_t_mul(vx, -rd);
-
-                    // ---- sample_light_source (renderer.cu:164-249), everything but the visibility walk ----
-                    bool shadow = false;
-                    f3 nee_dir = mk3(0, 0, 0);
-                    float s_init = kNoHit, s_stop = -1.0f;
-                    if (P.lst_count != 0) {
-                        int node_index = (int)((float)P.lst_count * rng_uniform(rng));
-                        GLight gl = P.glights[(uint32_t)node_index % P.lst_count];
-                        float p_lss = 1.0f / (float)P.lst_count; // times the area pdf for an emitter
-                        f3 radiance = ld3(gl.radiance);
-                        f3 A = ld3(gl.a), B = ld3(gl.b), C = ld3(gl.c);
-                        bool can_see = true; // false: the reference's walk cannot end on this light
-                        nee_kind = (int)gl.kind;
-                        if (gl.kind == 0) {
-                            f3 dl = A - position;
-                            float distance = length(dl);
-                            nee_dir = dl / distance;
-                            nee_dist = distance;
-                            radiance = radiance / (distance * distance);
-                            s_init = distance + distance * kBand;
-                            s_stop = distance - distance * kBand;
-                        } else if (gl.kind == 1) {
-                            nee_dir = A;
-                            s_init = kNoHit; // visible iff nothing at all is hit: stop at the first hit
-                            s_stop = kNoHit;
-                        } else {
-                            float u1, u2;
-                            do {
-                                u1 = rng_uniform(rng);
-                                u2 = rng_uniform(rng);
-                            } while (u1 + u2 > 1);
-                            f3 light_pos = (A + u1 * (B - A)) + u2 * (C - A);
-                            nee_dir = normalize(light_pos - position);
-                            nee_face = (int32_t)gl.face;
-                            // distance at which this ray meets the emitter itself (same arithmetic as the
-                            // walk's triangle test); without such a hit the emitter cannot be the closest face
-                            f3 so = position + 1e-6f * normal;
-                            f3 e1 = B - A, e2 = C - A;
-                            f3 pvec = cross(nee_dir, e2);
-                            float det = dot(e1, pvec);
-                            float t_f = -1.0f;
-                            if (!(det > -PT_EPS_UP && det < PT_EPS_UP)) {
-                                float inv_det = 1.0f / det;
-                                f3 tvec = so - A;
-                                float uu = dot(tvec, pvec) * inv_det;
-                                if (!(uu <= -PT_EPS_UP || uu > 1.0f)) {
-                                    f3 qvec = cross(tvec, e1);
-                                    float vv = dot(nee_dir, qvec) * inv_det;
-                                    if (!(vv <= -PT_EPS_UP || (uu + vv) > 1.0f)) t_f = dot(e2, qvec) * inv_det;
-                                }
-                            }
-                            if (t_f > 0) {
-                                s_init = t_f + t_f * kBand;
-                                s_stop = t_f - t_f * kBand;
-                                // sample_area_light, renderer.cu:131-133, with the emitter's baked normal and area
-                                float cos_theta_y = __builtin_fabsf(dot(ld3(gl.normal), nee_dir));
-                                float p_als = t_f * t_f / (gl.area * cos_theta_y);
-                                p_lss = p_lss * p_als;
-                            } else {
-                                can_see = false;
-                            }
-                        }
-                        if (can_see && p_lss > 0) {
-                            f3 l_ts = tbn_t_mul(vx, nee_dir);
-                            float p_brdf = brdf_pdf();
-                            f3 f_cos = brdf_eval(vx.brdf, vx.wo_ts, l_ts);
-                            f3 direct = f_cos * radiance;
-                            float weight = p_lss / (p_lss + p_brdf);
-                            direct_c = ((weight / p_lss) * thr) * direct;
-                            shadow = true;
-                        } else {
-                            if (COUNT) n.rays++; // the reference still traced this shadow ray
-                        }
-                    }
-
-                    // ---- BRDF::sample (brdf.cu:180-192) + next ray (renderer.cu:345-350) ----
-                    region_tick<COUNT>(n, kRegBsdf);
-                    f3 r;
-                    do {
-                        r.x = 2 * rng_uniform(rng) - 1;
-                        r.y = 2 * rng_uniform(rng) - 1;
-                        r.z = 2 * rng_uniform(rng) - 1;
-                    } while (dot(r, r) > 1);
-                    f3 wi = normalize(r);
-                    wi.z = __builtin_fabsf(wi.z);
-                    f_cos_next = brdf_eval(vx.brdf, vx.wo_ts, wi);
-                    if (COUNT) {
-                        n.bounces++;
-                        // the reference walks the BVH once per emissive LST node for the pdf
-                        n.rays += P.lst_face_nodes;
-                    }
-                    rd_next = tbn_mul(vx, wi);
-                    ro = position + 1e-6f * normal;
-                    if (shadow) {
-                        rd = nee_dir;
-                        mode = kModeNee;
-                        t_init = s_init;
-                        t_stop = s_stop;
-                    } else {
-                        rd = rd_next;
-                        pending = true;
-                    }
-                }
-            }
-        }
+        const bool end_path = vertex_handler<COUNT>(P, hit, s, n);
         region_time<COUNT>(n, kRegMain, tsh0, stamp<COUNT>());
         if (end_path) {
-            total = total + light;
+            total = total + s.light;
             sample++;
             need_camera = true;
             if (sample >= P.current_samples) alive = false;

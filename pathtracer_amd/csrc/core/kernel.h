@@ -790,7 +790,7 @@ PT_DEV void shadow_result(const HitLite &h, Path &s, Tally &n) {
 
 // Main-ray result: one handler per path vertex. Returns true when the path ended (the caller adds
 // s.light to the pixel and starts the next sample); otherwise s holds the next ray.
-template <bool COUNT>
+template <bool COUNT, bool MATERIAL_FROM_SHADE = false>
 PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n) {
     // ---- main-ray result: one handler per path vertex ----
     region_tick<COUNT>(n, kRegMain);
@@ -801,7 +801,7 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
     GMaterial m;
     if (sh) { // both records are addressed by the walk's result, so the two fetches overlap
         gs = P.shade[hit.face];
-        m = P.materials[hit.material];
+        m = P.materials[MATERIAL_FROM_SHADE ? gs.material : hit.material];
     }
     if (s.pending) {
         // evaluate_direct_p: only the LST node whose face this ray hit contributes

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "kernel.h"
+#include "queue.h"
 #include "layout.h"
 #include "ptcore.h"
 
@@ -152,6 +153,13 @@ struct pt_context {
     DeviceArray<uint32_t> tile_cost, tile_key, tile_order; // one entry per 8x8 tile
     bool order_valid = false;                    // tile_order holds a permutation for this resolution
 
+    // queue formulation (queue.h): path state of every pixel slot, hits, two live lists, counters
+    DeviceArray<float4> q_state, q_hit;
+    DeviceArray<uint32_t> q_list0, q_list1, q_cnt;
+    uint32_t *h_cnt = nullptr; // pinned copy of q_cnt
+    int walk_grid = 0;         // resident waves of the persistent walk kernel
+    bool use_queue = false;    // PT_KERNEL=queue at pt_create
+
     bool have_scene = false, have_bvh = false, have_lst = false, have_cfg = false;
     uint32_t face_count = 0, light_count = 0;
     int bvh_height = 0;
@@ -207,6 +215,74 @@ dim3 grid_of(const pt_context *ctx) {
     return dim3((waves + per_block - 1) / per_block);
 }
 
+// PT_KERNEL=queue (read at pt_create) selects the queue formulation of queue.h. It is bit-identical
+// and 3x slower (one device-wide barrier per path vertex, each as long as the longest walk), so the
+// default stays render_kernel; kept as the measured baseline for a barrier-free scheduler.
+
+int queue_alloc(pt_context *ctx) {
+    size_t tiles = (size_t)((ctx->P.width + 7) / 8) * (size_t)((ctx->P.height + 7) / 8), slots = tiles * 64;
+    if (ctx->q_hit.count == slots) return 0;
+    ctx->q_state.release(); ctx->q_hit.release(); ctx->q_list0.release(); ctx->q_list1.release(); ctx->q_cnt.release();
+    ctx->q_state.count = slots * qChunks;
+    ctx->q_hit.count = slots;
+    ctx->q_list0.count = ctx->q_list1.count = slots;
+    ctx->q_cnt.count = 4;
+    HIP_TRY(hipMalloc((void **)&ctx->q_state.ptr, ctx->q_state.bytes()));
+    HIP_TRY(hipMalloc((void **)&ctx->q_hit.ptr, ctx->q_hit.bytes()));
+    HIP_TRY(hipMalloc((void **)&ctx->q_list0.ptr, ctx->q_list0.bytes()));
+    HIP_TRY(hipMalloc((void **)&ctx->q_list1.ptr, ctx->q_list1.bytes()));
+    HIP_TRY(hipMalloc((void **)&ctx->q_cnt.ptr, ctx->q_cnt.bytes()));
+    if (!ctx->h_cnt) HIP_TRY(hipHostMalloc((void **)&ctx->h_cnt, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    if (!ctx->walk_grid) {
+        int per_cu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, queue_walk_kernel<32>, 64, 0));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        ctx->walk_grid = per_cu * cus;
+        if (ctx->walk_grid <= 0) return fail("queue_alloc: no occupancy for the walk kernel");
+    }
+    return 0;
+}
+
+// One batch with the queue kernels. Blocks the host between groups of iterations (it has to
+// learn when the last pixel finished); the stream is idle when it returns.
+int render_queue(pt_context *ctx, float *img, hipStream_t st) {
+    if (queue_alloc(ctx)) return 1;
+    QueueParams Q;
+    Q.state = ctx->q_state.ptr;
+    Q.hit = ctx->q_hit.ptr;
+    Q.list[0] = ctx->q_list0.ptr;
+    Q.list[1] = ctx->q_list1.ptr;
+    Q.cnt = ctx->q_cnt.ptr;
+    Q.slots = (uint32_t)ctx->q_hit.count;
+    ctx->P.tile_order = nullptr;
+    ctx->P.tile_cost = nullptr;
+    const KernelParams &P = ctx->P;
+    HIP_TRY(hipMemsetAsync(Q.cnt, 0, 4 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(queue_init_kernel, dim3(Q.slots / 64), dim3(64), 0, st, P, Q);
+    uint32_t live = (uint32_t)P.width * (uint32_t)P.height; // upper bound on the live pixels, refreshed per group
+    int cur = 0;
+    const int group = 16;
+    while (live != 0) {
+        for (int k = 0; k < group; k++) {
+            uint32_t blocks = (live + 63u) / 64u;
+            uint32_t wgrid = blocks < (uint32_t)ctx->walk_grid ? blocks : (uint32_t)ctx->walk_grid;
+            if (ctx->bvh_height <= 33)
+                hipLaunchKernelGGL((queue_walk_kernel<32>), dim3(wgrid), dim3(64), 0, st, P, Q, cur);
+            else
+                hipLaunchKernelGGL((queue_walk_kernel<64>), dim3(wgrid), dim3(64), 0, st, P, Q, cur);
+            hipLaunchKernelGGL(queue_shade_kernel, dim3(blocks), dim3(64), 0, st, P, Q, cur);
+            cur ^= 1;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->h_cnt, Q.cnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        live = ctx->h_cnt[cur];
+    }
+    hipLaunchKernelGGL(queue_final_kernel, dim3(Q.slots / 64), dim3(64), 0, st, P, Q, img);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned long long *counters, hipStream_t st) {
     dim3 grid = grid_of(ctx), block(kBlock);
     ctx->P.tile_order = (ctx->order_valid && g_lpt) ? ctx->tile_order.ptr : nullptr;
@@ -241,6 +317,8 @@ extern "C" int pt_create(int device, pt_context **out) {
     unsigned long long zeros[32] = {0};
     if (ctx->counters.upload(zeros, 32)) return 1;
     ctx->P.jump = ctx->jump.ptr;
+    const char *kernel = getenv("PT_KERNEL");
+    ctx->use_queue = kernel && strcmp(kernel, "queue") == 0;
     *out = ctx;
     return 0;
 }
@@ -264,6 +342,8 @@ extern "C" void pt_destroy(pt_context *ctx) {
     ctx->tile_cost.release();
     ctx->tile_order.release();
     ctx->tile_key.release();
+    ctx->q_state.release(); ctx->q_hit.release(); ctx->q_list0.release(); ctx->q_list1.release(); ctx->q_cnt.release();
+    if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
     for (int i = 0; i < pt_context::kEventRing; i++) {
         if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
         if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
@@ -500,11 +580,16 @@ extern "C" int pt_render_batch_into(pt_context *ctx, float *device_img, void *st
     set_launch(ctx, seed, previous_samples, current_samples, 1);
     const int slot = (int)(ctx->launches % pt_context::kEventRing);
     HIP_TRY(hipEventRecord(ctx->ev_start[slot], st));
-    launch_render<false>(ctx, device_img, nullptr, st);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));
-    launch_rank(ctx, st);
-    HIP_TRY(hipGetLastError());
+    if (ctx->use_queue) {
+        if (render_queue(ctx, device_img, st)) return 1;
+        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));
+    } else {
+        launch_render<false>(ctx, device_img, nullptr, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));
+        launch_rank(ctx, st);
+        HIP_TRY(hipGetLastError());
+    }
     ctx->launches++;
     return 0;
 }
@@ -615,5 +700,6 @@ extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
     if (!ctx) return 0;
     return ctx->nodes.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
            ctx->lst.bytes() + ctx->glights.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes() +
-           ctx->tile_cost.bytes() + ctx->tile_key.bytes() + ctx->tile_order.bytes();
+           ctx->tile_cost.bytes() + ctx->tile_key.bytes() + ctx->tile_order.bytes() +
+           ctx->q_state.bytes() + ctx->q_hit.bytes() + ctx->q_list0.bytes() + ctx->q_list1.bytes() + ctx->q_cnt.bytes();
 }

@@ -232,6 +232,21 @@ def test_single_leaf_tree_and_one_sample(renderer, scene_dir):
     assert gpu.max() > 0.3  # the emitter is in view
 
 
+def test_queue_formulation_is_bit_identical(cornell_like, monkeypatch):
+    """csrc/core/queue.h (PT_KERNEL=queue: path state in HBM, walk / shade kernels over a compacted
+    list) computes the same image as the product kernel and the oracle."""
+    monkeypatch.setenv("PT_KERNEL", "queue")
+    r = core.Renderer(0)
+    try:
+        w, h = 100, 52  # ragged tiles
+        o = _setup(r, cornell_like, w, h, exposure=0.5)
+        gpu = r.render(4, 7, 3)  # batches of 3, 3, 1
+        cpu = o.render(4, 7, 3)
+        _assert_images_match(gpu, cpu)
+    finally:
+        r.close()
+
+
 def test_counters_match_oracle(renderer, cornell_like):
     """Reference-equivalent ray count, samples, shaded hits and bounces are integers that must
     agree exactly; the kernel walks fewer trees than the reference traces rays."""

@@ -433,6 +433,7 @@ extern "C" int pt_scene_upload(pt_context *ctx, const pt_scene_desc *scene) {
     ctx->face_count = scene->face_count;
     ctx->light_count = scene->light_count;
     ctx->have_scene = true;
+    ctx->order_valid = false; // tile costs belong to one scene
     ctx->have_bvh = false; // a BVH belongs to one scene
     ctx->have_lst = false;
     return 0;
@@ -584,6 +585,14 @@ extern "C" int pt_render_batch_into(pt_context *ctx, float *device_img, void *st
         if (render_queue(ctx, device_img, st)) return 1;
         HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));
     } else {
+        if (g_lpt && !ctx->order_valid && current_samples >= 8) {
+            // No costs recorded yet for this scene/resolution: a 1-sample launch that writes no pixel
+            // (null image) records them, so that even the first batch is dispatched heaviest first.
+            ctx->P.current_samples = 1;
+            launch_render<false>(ctx, nullptr, nullptr, st);
+            launch_rank(ctx, st);
+            ctx->P.current_samples = current_samples;
+        }
         launch_render<false>(ctx, device_img, nullptr, st);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));

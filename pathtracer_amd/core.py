@@ -19,12 +19,17 @@ def _check(rc):
         raise CoreError(_ffi.core_lib().pt_last_error().decode("utf-8", "replace"))
 
 
+CONTEXTS_CREATED = 0  # > 0: this process has initialised the GPU (tests that spawn the CLI look at it)
+
+
 class Renderer:
     """One context = one GPU. Mirrors the device half of src/main.cu:74-111."""
 
     def __init__(self, device=0):
         self._lib = _ffi.core_lib()
         self._ctx = C.c_void_p()
+        global CONTEXTS_CREATED
+        CONTEXTS_CREATED += 1
         _check(self._lib.pt_create(int(device), C.byref(self._ctx)))
         self.device = int(device)
         self.width = self.height = 0

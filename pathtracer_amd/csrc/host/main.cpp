@@ -112,8 +112,8 @@ int main(int argc, char *argv[]) {
     pth_log(3, "Launching kernel... \n");
     pth_log(3, "Rendering %d samples in batches of %d, img size (%d, %d)\n", cfg.samples, cfg.samples_every_update,
             cfg.resolution_x, cfg.resolution_y);
-    pth_log(3, "Kernel params <<<(%d), (256)>>> (16x16-pixel blocks, one 8x8 tile per wave64)\n",
-            ((cfg.resolution_x + 15) / 16) * ((cfg.resolution_y + 15) / 16));
+    pth_log(3, "Kernel params <<<(%d), (64)>>> (one 8x8-pixel tile per wave64 workgroup)\n",
+            ((cfg.resolution_x + 7) / 8) * ((cfg.resolution_y + 7) / 8));
 
     auto start = std::chrono::system_clock::now();
     double kernel_seconds = 0;

@@ -1007,27 +1007,124 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 3
 #endif
-template <bool COUNT, int STACK>
-__global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
-    __shared__ uint32_t lds_stack[STACK * kBlock];
-    __shared__ unsigned long long lds_time[COUNT ? 8 * (kBlock / 64) : 1];
-    uint32_t *stack = lds_stack + threadIdx.x;
+#ifndef PT_SWAP_EVERY
+#define PT_SWAP_EVERY 5 /* samples a lane renders of one pixel before it hands the pixel back */
+#endif
+// A wave's tile is 8 x ROWS pixels (ROWS = 8: one pixel per lane; 16: two, see render_kernel).
+constexpr int kRing = 64;      // waiting pixels never exceed 8 * ROWS - 64 <= 64
+constexpr int kRingWords = 11; // pool index, 6 RNG words, 3 sum, samples done
+static_assert(kBlock == 64, "render_kernel is written for one-wave workgroups");
 
-    int px, py;
-    const uint32_t tile = pixel_of_thread(P, &px, &py);
+// The wave's tile. Static order: workgroups that share blockIdx % 8 share an XCD and its L2; XCD x
+// takes tile rows x, x+8, ... so every XCD sees the whole picture (balance) while horizontal
+// neighbours stay on one L2. Once a launch has recorded per-tile costs, tile_order lists the
+// tiles heaviest class first: the dispatcher hands out workgroups in index order, so the expensive
+// tiles start early and the cheap ones fill the tail.
+template <int ROWS>
+PT_DEV uint32_t tile_of_wave(const KernelParams &P, uint32_t *tx, uint32_t *ty) {
+    uint32_t ntx = ((uint32_t)P.width + 7u) / 8u, nty = ((uint32_t)P.height + (uint32_t)ROWS - 1u) / (uint32_t)ROWS;
+    uint32_t wave = blockIdx.x;
+    uint32_t x = wave % ntx, y = wave / ntx;
+    if (P.tile_order) {
+        uint32_t t = P.tile_order[wave];
+        x = t % ntx;
+        y = t / ntx;
+    } else if (nty % 8u == 0) {
+        uint32_t xcd = wave % 8u, i = wave / 8u;
+        x = i % ntx;
+        y = (i / ntx) * 8u + xcd;
+    }
+    *tx = x;
+    *ty = y;
+    return y * ntx + x;
+}
+
+template <int ROWS>
+PT_DEV void pool_pixel(uint32_t tx, uint32_t ty, uint32_t q, int *px, int *py) {
+    *px = (int)(tx * 8u + (q & 7u));
+    *py = (int)(ty * (uint32_t)ROWS + (q >> 3));
+}
+
+// A pixel between two turns, in the wave's LDS ring: word w of position p at ring[w * kRing + p].
+PT_DEV void ring_put(uint32_t *ring, uint32_t pos, uint32_t q, const Rng &g, f3 total, int sample) {
+    ring[0 * kRing + pos] = q;
+    ring[1 * kRing + pos] = g.v0; ring[2 * kRing + pos] = g.v1; ring[3 * kRing + pos] = g.v2;
+    ring[4 * kRing + pos] = g.v3; ring[5 * kRing + pos] = g.v4; ring[6 * kRing + pos] = g.d;
+    ring[7 * kRing + pos] = __float_as_uint(total.x);
+    ring[8 * kRing + pos] = __float_as_uint(total.y);
+    ring[9 * kRing + pos] = __float_as_uint(total.z);
+    ring[10 * kRing + pos] = (uint32_t)sample;
+}
+PT_DEV void ring_get(const uint32_t *ring, uint32_t pos, uint32_t &q, Rng &g, f3 &total, int &sample) {
+    q = ring[0 * kRing + pos];
+    g.v0 = ring[1 * kRing + pos]; g.v1 = ring[2 * kRing + pos]; g.v2 = ring[3 * kRing + pos];
+    g.v3 = ring[4 * kRing + pos]; g.v4 = ring[5 * kRing + pos]; g.d = ring[6 * kRing + pos];
+    g.extra = 0.f;    // a sample draws its two jitter normals as one Box-Muller pair (renderer.cu:376-380),
+    g.have_extra = 0; // so nothing is cached at a sample boundary
+    total = mk3(__uint_as_float(ring[7 * kRing + pos]), __uint_as_float(ring[8 * kRing + pos]), __uint_as_float(ring[9 * kRing + pos]));
+    sample = (int)ring[10 * kRing + pos];
+}
+
+// One wave renders a tile of kPool = 8 * ROWS pixels with 64 lanes. With ROWS = 16 a lane does NOT own a pixel for the whole
+// launch: after PT_SWAP_EVERY samples it swaps its pixel (RNG state, sum, count: 40 bytes) with the
+// one that has waited longest in the wave's LDS ring. A pixel's samples still run one after the
+// other in their own order (so every pixel's arithmetic is unchanged), but the 64 lanes stay busy
+// until the tile's last few samples instead of until each lane's own pixel is complete: with one
+// pixel per lane the slowest of 64 pixels took 1.27x the mean (21 % of all lane time idle).
+template <bool COUNT, int STACK, int ROWS>
+__global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
+    static_assert(ROWS >= 8 && ROWS <= 16, "tile rows");
+    constexpr int kPool = 8 * ROWS;
+    __shared__ uint32_t lds_stack[STACK * kBlock];
+    __shared__ uint32_t lds_ring[ROWS > 8 ? kRingWords * kRing : 1];
+    __shared__ unsigned long long lds_time[COUNT ? 8 : 1];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+
+    uint32_t tx, ty;
+    const uint32_t tile = tile_of_wave<ROWS>(P, &tx, &ty);
     const unsigned long long t_tile0 = P.tile_cost ? __builtin_amdgcn_s_memtime() : 0ull;
-    bool inside = px < P.width && py < P.height;
     Tally n = {};
     if (COUNT) {
-        n.w_time = lds_time + 8 * (threadIdx.x >> 6);
-        if ((threadIdx.x & 63) < 8) n.w_time[threadIdx.x & 63] = 0;
+        n.w_time = lds_time;
+        if (lane < 8) n.w_time[lane] = 0;
     }
     unsigned long long t_kernel0 = stamp<COUNT>();
 
     Path s = {};
-    rng_init(s.rng, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(py * P.width + px) : 0u);
-
     f3 total = mk3(0, 0, 0);
+    int sample = 0, turn = 0;
+    int q = -1; // the pool pixel this lane is rendering, -1 = none
+    int px = 0, py = 0;
+    bool need_camera = false;
+    bool need_switch = true; // lane is at a turn boundary (or idle)
+
+    // RNG init of every pixel of the tile: the first 64 start in their lanes, the rest wait in the ring
+    uint32_t head = 0, tail = 0; // wave-uniform running counters (ring position = counter & (kRing - 1))
+    for (uint32_t r = 0; r * 64u < (uint32_t)kPool; r++) {
+        uint32_t qq = r * 64u + lane;
+        int x, y;
+        pool_pixel<ROWS>(tx, ty, qq, &x, &y);
+        bool inside = qq < (uint32_t)kPool && x < P.width && y < P.height && P.current_samples > 0;
+        Rng g;
+        rng_init(g, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(y * P.width + x) : 0u);
+        if (r == 0) {
+            if (inside) {
+                s.rng = g;
+                q = (int)qq;
+                px = x;
+                py = y;
+                need_camera = true;
+                need_switch = false;
+            }
+        } else {
+            unsigned long long m = __builtin_amdgcn_ballot_w64(inside);
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (inside && ROWS > 8) ring_put(lds_ring, (tail + rank) & (kRing - 1), qq, g, mk3(0, 0, 0), 0);
+            tail += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+
     s.thr = mk3(1, 1, 1);
     s.rd = s.rd_next = mk3(0, 0, 1);
     s.rr_prob = 1.f;
@@ -1036,20 +1133,68 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
     s.t_stop = -1.0f;
     s.mode = kModeMain;
     Walk wk = {};
+    wk.ref = kDone;
     bool walking = false;
-    int sample = 0;
-    bool need_camera = true;
-    bool alive = inside && P.current_samples > 0;
 
-    while (alive) {
+    for (;;) {
+        // ---- turn boundary: swap the pixel with the one that has waited longest ----
+        if (__builtin_amdgcn_ballot_w64(need_switch && (q >= 0 || head != tail)) != 0) {
+            const bool more = q >= 0 && sample < P.current_samples; // this lane's pixel is not complete
+            if (need_switch && q >= 0 && !more && img) { // complete: running-mean blend, renderer.cu:393-404
+                f3 mean = total * P.exposure_scale;
+                mean = mean / (float)P.current_samples;
+                int total_samples = P.previous_samples + P.current_samples;
+                float *p = img + 3 * ((size_t)py * (size_t)P.width + (size_t)px);
+                f3 last = mk3(p[0], p[1], p[2]);
+                f3 next = last * ((float)P.previous_samples / (float)total_samples) +
+                          mean * ((float)P.current_samples / (float)total_samples);
+                p[0] = next.x;
+                p[1] = next.y;
+                p[2] = next.z;
+            }
+            // take (reads come before this step's writes, so a full ring may be refilled in place)
+            unsigned long long m_take = __builtin_amdgcn_ballot_w64(need_switch);
+            uint32_t r_take = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_take >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_take, 0));
+            uint32_t n_avail = tail - head, n_take = (uint32_t)__builtin_popcountll(m_take);
+            const bool got = need_switch && r_take < n_avail;
+            uint32_t new_q = 0;
+            Rng new_rng = s.rng;
+            f3 new_total = total;
+            int new_sample = sample;
+            if (got && ROWS > 8) ring_get(lds_ring, (head + r_take) & (kRing - 1), new_q, new_rng, new_total, new_sample);
+            head += n_take < n_avail ? n_take : n_avail;
+            // give
+            const bool give = got && more;
+            unsigned long long m_give = __builtin_amdgcn_ballot_w64(give);
+            uint32_t r_give = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_give >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_give, 0));
+            if (give && ROWS > 8) ring_put(lds_ring, (tail + r_give) & (kRing - 1), (uint32_t)q, s.rng, total, sample);
+            tail += (uint32_t)__builtin_popcountll(m_give);
+            if (got) {
+                q = (int)new_q;
+                s.rng = new_rng;
+                total = new_total;
+                sample = new_sample;
+                pool_pixel<ROWS>(tx, ty, new_q, &px, &py);
+            } else if (need_switch && !more) {
+                q = -1; // completed or idle, and nothing waits
+            }
+            if (need_switch && q >= 0) { // a new pixel, or nobody waited and this one goes on
+                turn = 0;
+                need_camera = true;
+                need_switch = false;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(q >= 0) == 0) break; // no pixel in flight and none waiting
+
         if (need_camera) {
             start_sample<COUNT>(P, px, py, s, n);
             need_camera = false;
         }
 
-        region_tick<COUNT>(n, kRegLoop);
+        const bool active = q >= 0;
+        if (active) region_tick<COUNT>(n, kRegLoop);
         unsigned long long tl0 = stamp<COUNT>();
-        if (!walking) { // start the walk of the ray set up by the previous iteration
+        if (active && !walking) { // start the walk of the ray set up by the previous iteration
             wk.ref = P.root;
             wk.pleaf = 0;
             wk.sp = 0;
@@ -1067,7 +1212,7 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
         }
         walk_slice<COUNT, STACK>(P, s.ro, s.rd, s.t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
-        const bool finished = wk.ref == kDone && wk.pleaf == 0;
+        const bool finished = active && wk.ref == kDone && wk.pleaf == 0;
 
         if (finished && s.mode == kModeNee) { // shadow results are handled on the spot
             unsigned long long tn0 = stamp<COUNT>();
@@ -1080,11 +1225,11 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
 #if PT_SHADE_NUM > 0
         { // run the vertex handler only once enough of the wave's live lanes wait for it (wave-uniform)
             int n_fin = __builtin_popcountll(__builtin_amdgcn_ballot_w64(finished));
-            int n_live = __builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+            int n_live = __builtin_popcountll(__builtin_amdgcn_ballot_w64(active));
             if (n_fin != n_live && n_fin * PT_SHADE_DEN < n_live * PT_SHADE_NUM) continue;
         }
 #endif
-        if (!finished) continue; // still walking: next slice
+        if (!finished) continue; // still walking (or idle): next slice
         unsigned long long tsh0 = stamp<COUNT>();
         walking = false;
         HitLite hit = wk.h;
@@ -1096,26 +1241,13 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
         if (end_path) {
             total = total + s.light;
             sample++;
-            need_camera = true;
-            if (sample >= P.current_samples) alive = false;
+            turn++;
+            if (sample >= P.current_samples || turn >= PT_SWAP_EVERY) need_switch = true;
+            else need_camera = true;
         }
     }
 
-    if (inside) {
-        total = total * P.exposure_scale;
-        total = total / (float)P.current_samples;
-        int total_samples = P.previous_samples + P.current_samples;
-        float *p = img + 3 * ((size_t)py * (size_t)P.width + (size_t)px);
-        if (img) {
-            f3 last = mk3(p[0], p[1], p[2]);
-            f3 next = last * ((float)P.previous_samples / (float)total_samples) +
-                      total * ((float)P.current_samples / (float)total_samples);
-            p[0] = next.x;
-            p[1] = next.y;
-            p[2] = next.z;
-        }
-    }
-    if (P.tile_cost && (threadIdx.x & 63) == 0) { // ticks this tile kept a wave slot busy, clamped to 32 bits
+    if (P.tile_cost && lane == 0) { // ticks this tile kept a wave slot busy, clamped to 32 bits
         unsigned long long dt = __builtin_amdgcn_s_memtime() - t_tile0;
         P.tile_cost[tile] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
     }
@@ -1133,7 +1265,7 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
         }
         for (int k = 0; k < 3; k++)
             if (n.w_idle[k]) atomicAdd(&counters[27 + k], (unsigned long long)n.w_idle[k]);
-        if ((threadIdx.x & 63) == 0) { // lane 0 always reaches the end of the kernel
+        if (lane == 0) {
             for (int k = 0; k < 6; k++) atomicAdd(&counters[20 + k], n.w_time[k]);
             atomicAdd(&counters[26], stamp<COUNT>() - t_kernel0); // wave lifetime
         }

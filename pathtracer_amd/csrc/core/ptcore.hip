@@ -150,8 +150,9 @@ struct pt_context {
     DeviceArray<uint32_t> jump;
     DeviceArray<float> image;
     DeviceArray<unsigned long long> counters;
-    DeviceArray<uint32_t> tile_cost, tile_key, tile_order; // one entry per 8x8 tile
+    DeviceArray<uint32_t> tile_cost, tile_key, tile_order; // one entry per tile (sized for 8x8 tiles)
     bool order_valid = false;                    // tile_order holds a permutation for this resolution
+    int tile_rows = 8;                           // render_kernel's tile is 8 x tile_rows pixels (8 or 16)
 
     // queue formulation (queue.h): path state of every pixel slot, hits, two live lists, counters
     DeviceArray<float4> q_state, q_hit;
@@ -197,10 +198,17 @@ void set_launch(pt_context *ctx, int seed, int prev, int cur, int jitter) {
 // PT_LPT=0 in the environment keeps the static tile order (A/B measurements)
 const bool g_lpt = []() { const char *e = getenv("PT_LPT"); return !(e && e[0] == '0'); }();
 
+// Tiles of render_kernel: 8 x tile_rows pixels, one per wave.
+void render_tiles(const pt_context *ctx, uint32_t *ntx, uint32_t *nty) {
+    *ntx = ((uint32_t)ctx->P.width + 7u) / 8u;
+    *nty = ((uint32_t)ctx->P.height + (uint32_t)ctx->tile_rows - 1u) / (uint32_t)ctx->tile_rows;
+}
+
 // Ranks the tiles by the cost the launch before it recorded (same stream, so ordered after it).
 void launch_rank(pt_context *ctx, hipStream_t st) {
     if (!g_lpt) return;
-    uint32_t ntx = ((uint32_t)ctx->P.width + 7u) / 8u, nty = ((uint32_t)ctx->P.height + 7u) / 8u;
+    uint32_t ntx, nty;
+    render_tiles(ctx, &ntx, &nty);
     uint32_t n = ntx * nty;
     if (n >= (1u << 24)) return; // keys hold the static position in 24 bits; larger images keep the static order
     dim3 grid((n + 255u) / 256u), block(256);
@@ -284,13 +292,19 @@ int render_queue(pt_context *ctx, float *img, hipStream_t st) {
 }
 
 template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned long long *counters, hipStream_t st) {
-    dim3 grid = grid_of(ctx), block(kBlock);
+    uint32_t ntx, nty;
+    render_tiles(ctx, &ntx, &nty);
+    dim3 grid(ntx * nty), block(kBlock);
     ctx->P.tile_order = (ctx->order_valid && g_lpt) ? ctx->tile_order.ptr : nullptr;
     ctx->P.tile_cost = g_lpt ? ctx->tile_cost.ptr : nullptr;
-    if (ctx->bvh_height <= 33)
-        hipLaunchKernelGGL((render_kernel<COUNT, 32>), grid, block, 0, st, ctx->P, img, counters);
-    else
-        hipLaunchKernelGGL((render_kernel<COUNT, 64>), grid, block, 0, st, ctx->P, img, counters);
+    const bool tall = ctx->bvh_height > 33;
+    if (ctx->tile_rows == 16) {
+        if (!tall) hipLaunchKernelGGL((render_kernel<COUNT, 32, 16>), grid, block, 0, st, ctx->P, img, counters);
+        else hipLaunchKernelGGL((render_kernel<COUNT, 64, 16>), grid, block, 0, st, ctx->P, img, counters);
+    } else {
+        if (!tall) hipLaunchKernelGGL((render_kernel<COUNT, 32, 8>), grid, block, 0, st, ctx->P, img, counters);
+        else hipLaunchKernelGGL((render_kernel<COUNT, 64, 8>), grid, block, 0, st, ctx->P, img, counters);
+    }
 }
 
 } // namespace
@@ -549,6 +563,19 @@ extern "C" int pt_configure(pt_context *ctx, const pt_render_config *cfg) {
         HIP_TRY(hipMalloc((void **)&ctx->image.ptr, n * sizeof(float)));
     }
     HIP_TRY(hipMemset(ctx->image.ptr, 0, n * sizeof(float)));
+    // Two pixels per lane (8x16 tiles, pixels swapped between lanes every few samples) keep the lanes of
+    // a wave busy to the end of its tile, but halve the number of tiles; that pays only while the
+    // launch still has many tiles per wave slot (measured: a loss at 1024^2).
+    {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        size_t tiles16 = (size_t)((P.width + 7) / 8) * (size_t)((P.height + 15) / 16);
+        size_t slots = (size_t)cus * 4 * PT_MIN_WAVES;
+        int rows = tiles16 >= 8 * slots ? 16 : 8;
+        if (const char *e = getenv("PT_TILE_ROWS")) rows = atoi(e) == 16 ? 16 : 8;
+        if (rows != ctx->tile_rows) ctx->order_valid = false;
+        ctx->tile_rows = rows;
+    }
     size_t tiles = (size_t)((P.width + 7) / 8) * (size_t)((P.height + 7) / 8);
     if (ctx->tile_cost.count != tiles) {
         ctx->tile_cost.release();

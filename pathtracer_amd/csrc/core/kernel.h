@@ -420,7 +420,7 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
 //    on to shading and come back with a new ray; lanes still walking keep (ref, sp, pleaf, h)
 //    and resume in the next slice. One very long walk no longer holds 63 lanes hostage.
 #ifndef PT_SLICE
-#define PT_SLICE 16
+#define PT_SLICE 12
 #endif
 #ifndef PT_SHADE_NUM
 #define PT_SHADE_NUM 0 /* shade when finished lanes / live lanes >= NUM / DEN (0 = as soon as any lane finished) */
@@ -429,7 +429,7 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
 #define PT_SHADE_DEN 4
 #endif
 #ifndef PT_BLOCKED_SHIFT
-#define PT_BLOCKED_SHIFT 1 /* leave the node loop when blocked lanes >= stepping lanes >> shift */
+#define PT_BLOCKED_SHIFT 0 /* leave the node loop when blocked lanes >= stepping lanes >> shift */
 #endif
 
 struct Walk {
@@ -1072,7 +1072,7 @@ PT_DEV void ring_get(const uint32_t *ring, uint32_t pos, uint32_t &q, Rng &g, f3
 // until the tile's last few samples instead of until each lane's own pixel is complete: with one
 // pixel per lane the slowest of 64 pixels took 1.27x the mean (21 % of all lane time idle).
 template <bool COUNT, int STACK, int ROWS>
-__global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
+PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned long long *counters) {
     static_assert(ROWS >= 8 && ROWS <= 16, "tile rows");
     constexpr int kPool = 8 * ROWS;
     __shared__ uint32_t lds_stack[STACK * kBlock];
@@ -1242,7 +1242,7 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
             total = total + s.light;
             sample++;
             turn++;
-            if (sample >= P.current_samples || turn >= PT_SWAP_EVERY) need_switch = true;
+            if (sample >= P.current_samples || (ROWS > 8 && turn >= PT_SWAP_EVERY)) need_switch = true;
             else need_camera = true;
         }
     }
@@ -1270,6 +1270,18 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelPara
             atomicAdd(&counters[26], stamp<COUNT>() - t_kernel0); // wave lifetime
         }
     }
+}
+
+template <bool COUNT, int STACK, int ROWS>
+__global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
+    render_body<COUNT, STACK, ROWS>(P, img, counters);
+}
+
+// The same code under its own name, for the 1-sample launch that records tile costs before the first
+// batch of a scene (no image): profiles then show the batches and the probe as separate kernels.
+template <int STACK, int ROWS>
+__global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) cost_probe_kernel(KernelParams P) {
+    render_body<false, STACK, ROWS>(P, nullptr, nullptr);
 }
 
 // First camera ray of every pixel: face id + distance (parity probe).

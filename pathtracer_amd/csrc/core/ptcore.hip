@@ -307,6 +307,23 @@ template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned l
     }
 }
 
+// 1-sample launch without an image: records the tile costs (see pt_render_batch_into).
+void launch_probe(pt_context *ctx, hipStream_t st) {
+    uint32_t ntx, nty;
+    render_tiles(ctx, &ntx, &nty);
+    dim3 grid(ntx * nty), block(kBlock);
+    ctx->P.tile_order = nullptr;
+    ctx->P.tile_cost = ctx->tile_cost.ptr;
+    const bool tall = ctx->bvh_height > 33;
+    if (ctx->tile_rows == 16) {
+        if (!tall) hipLaunchKernelGGL((cost_probe_kernel<32, 16>), grid, block, 0, st, ctx->P);
+        else hipLaunchKernelGGL((cost_probe_kernel<64, 16>), grid, block, 0, st, ctx->P);
+    } else {
+        if (!tall) hipLaunchKernelGGL((cost_probe_kernel<32, 8>), grid, block, 0, st, ctx->P);
+        else hipLaunchKernelGGL((cost_probe_kernel<64, 8>), grid, block, 0, st, ctx->P);
+    }
+}
+
 } // namespace
 
 extern "C" const char *pt_last_error(void) { return g_error; }
@@ -616,7 +633,7 @@ extern "C" int pt_render_batch_into(pt_context *ctx, float *device_img, void *st
             // No costs recorded yet for this scene/resolution: a 1-sample launch that writes no pixel
             // (null image) records them, so that even the first batch is dispatched heaviest first.
             ctx->P.current_samples = 1;
-            launch_render<false>(ctx, nullptr, nullptr, st);
+            launch_probe(ctx, st);
             launch_rank(ctx, st);
             ctx->P.current_samples = current_samples;
         }

@@ -232,6 +232,22 @@ def test_single_leaf_tree_and_one_sample(renderer, scene_dir):
     assert gpu.max() > 0.3  # the emitter is in view
 
 
+def test_two_pixels_per_lane_tiles(cornell_like, monkeypatch):
+    """Large images use 8x16 tiles whose 128 pixels are swapped between the 64 lanes every few
+    samples (PT_TILE_ROWS=16 forces that kernel at a small size): ragged right and top edges, more
+    samples than one turn, several launches."""
+    monkeypatch.setenv("PT_TILE_ROWS", "16")
+    r = core.Renderer(0)
+    try:
+        w, h = 100, 70
+        o = _setup(r, cornell_like, w, h)
+        gpu = r.render(21, 26, 12)  # launches of 12, 12, 2 samples
+        cpu = o.render(21, 26, 12)
+        _assert_images_match(gpu, cpu)
+    finally:
+        r.close()
+
+
 def test_queue_formulation_is_bit_identical(cornell_like, monkeypatch):
     """csrc/core/queue.h (PT_KERNEL=queue: path state in HBM, walk / shade kernels over a compacted
     list) computes the same image as the product kernel and the oracle."""

@@ -33,11 +33,13 @@ SEED = 42
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(c, width, height):
-    """64 B per inner-node visit (two child boxes + two references), 40 B per
-    triangle test (positions + id), 240 B per shaded hit (face + 3 x (normal, tangent, uv) +
-    material), 24 B per pixel per launch (accumulator read + write)."""
-    return 64 * c["inner_visits"] + 40 * c["tri_tests"] + 240 * c["shaded_hits"] + 24 * width * height
+def algorithmic_bytes(c, width, height, tree=2):
+    """64 B per inner-node visit (two child boxes + two references; 128 B when the
+    launch walked the four-wide form of the tree, four boxes + four references), 40 B per triangle
+    test (positions + id), 240 B per shaded hit (face + 3 x (normal, tangent, uv) + material), 24 B
+    per pixel per launch (accumulator read + write)."""
+    node = 128 if tree == 4 else 64
+    return node * c["inner_visits"] + 40 * c["tri_tests"] + 240 * c["shaded_hits"] + 24 * width * height
 
 
 def cpu_baseline(scene, bvh, lst, threads):
@@ -147,7 +149,8 @@ def main():
         samples = WIDTH * HEIGHT * spp_total
         counters = r.count_batch(SEED, SPP_PER_STEP)  # instrumented variant, first timed batch, untimed
         avg_ms = sum(kernel_ms) / len(kernel_ms)
-        abytes = algorithmic_bytes(counters, WIDTH, HEIGHT)
+        tree = r.walk_tree()
+        abytes = algorithmic_bytes(counters, WIDTH, HEIGHT, tree)
         achieved = abytes / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic()
         out = {
@@ -158,7 +161,7 @@ def main():
             "config": {"workload": "many_lights STAND-IN (room+point+sun+emitter, 322804 tris) 1024x1024, "
                                    f"{SPP_PER_STEP} spp per step, seed 42+batch", "resolution": [WIDTH, HEIGHT],
                        "spp_per_step": SPP_PER_STEP, "spp_total": spp_total, "parallelism": f"sample-shard x{world}",
-                       "bvh_nodes": int(bvh.node_count), "faces": int(len(scene.faces)), "lst_nodes": int(len(lst.nodes))},
+                       "walk_tree": tree, "bvh_nodes": int(bvh.node_count), "faces": int(len(scene.faces)), "lst_nodes": int(len(lst.nodes))},
             "kernel_ms_per_step": round(avg_ms, 3),
             "kernel_msamples_per_s": round(WIDTH * HEIGHT * SPP_PER_STEP / (avg_ms * 1e-3) / 1e6, 3),
             "mrays_per_s": round(counters["rays"] / (avg_ms * 1e-3) / 1e6 * world, 2),

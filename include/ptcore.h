@@ -133,6 +133,12 @@ float pt_last_kernel_ms(pt_context *ctx);
  * no such launch. */
 float pt_kernel_ms(pt_context *ctx, int launches_back);
 
+/* Which form of the uploaded tree the render launches walk: 2 = the reference's binary tree, 4 = the
+ * same tree folded four-wide at upload, 0 = not chosen yet. Both give the same hits; the first render
+ * launch after pt_bvh_upload times a 2-sample launch on each and keeps the faster (PT_TREE=binary|wide
+ * in the environment forces one). */
+int pt_walk_tree(pt_context *ctx);
+
 /* Bytes of device memory held by the context (scene + BVH + LST + image). */
 uint64_t pt_device_footprint(pt_context *ctx);
 

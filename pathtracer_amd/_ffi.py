@@ -193,6 +193,7 @@ def core_lib():
     L.pt_last_kernel_ms.restype = C.c_float
     L.pt_kernel_ms.argtypes = [C.c_void_p, C.c_int]
     L.pt_kernel_ms.restype = C.c_float
+    L.pt_walk_tree.argtypes = [C.c_void_p]
     L.pt_device_footprint.argtypes = [C.c_void_p]
     L.pt_device_footprint.restype = C.c_uint64
     _core = L

@@ -107,6 +107,10 @@ class Renderer:
         """HIP-event duration of an earlier render launch (0 = the most recent one)."""
         return float(self._lib.pt_kernel_ms(self._ctx, int(launches_back)))
 
+    def walk_tree(self):
+        """2 = binary tree, 4 = four-wide, 0 = not chosen yet (see include/ptcore.h)."""
+        return int(self._lib.pt_walk_tree(self._ctx))
+
     def device_footprint(self):
         return int(self._lib.pt_device_footprint(self._ctx))
 

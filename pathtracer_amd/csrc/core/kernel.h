@@ -77,7 +77,8 @@ struct Texture {
 
 struct KernelParams {
     // geometry
-    const GNode *nodes;
+    const GNode *nodes;   // binary tree: rays with an infinite direction reciprocal, probes
+    const GNode4 *nodes4; // the same tree folded four-wide: every other ray
     const GTri *tris;
     const GShade *shade;
     const GMaterial *materials;
@@ -86,7 +87,7 @@ struct KernelParams {
     const GLight *glights; // one baked record per LST node
     const Texture *textures;
     const uint32_t *jump; // [32][160][8] words: XORWOW A^(2^67 * 2^k), rows padded to 8
-    uint32_t root;
+    uint32_t root, root4;
     uint32_t lst_count;
     uint32_t lst_face_nodes; // LST nodes that are emissive faces (one light-pdf ray each in the reference)
     int32_t clear_texture;
@@ -100,6 +101,7 @@ struct KernelParams {
     uint32_t seed_lo, seed_hi;
     int32_t previous_samples, current_samples;
     int32_t jitter; // primary-hit probe only
+
     // launch order of the 8x8 tiles (heaviest first, from the previous launch's per-tile cost); both may be null
     const uint32_t *tile_order;
     uint32_t *tile_cost;
@@ -416,11 +418,15 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
 //  * Wave-uniform phases: the node loop runs while no lane is blocked (holding a parked leaf
 //    AND standing on another one), so no lane idles while others descend; then one leaf phase
 //    serves every parked leaf.
-//  * Time slicing: a slice ends after PT_SLICE node iterations. Lanes whose walk finished go
+//  * Time slicing: a slice ends after a fixed number of node iterations (PT_SLICE in the binary tree,
+//    PT_SLICE_WIDE in the four-wide one). Lanes whose walk finished go
 //    on to shading and come back with a new ray; lanes still walking keep (ref, sp, pleaf, h)
 //    and resume in the next slice. One very long walk no longer holds 63 lanes hostage.
 #ifndef PT_SLICE
 #define PT_SLICE 12
+#endif
+#ifndef PT_SLICE_WIDE
+#define PT_SLICE_WIDE 6
 #endif
 #ifndef PT_SHADE_NUM
 #define PT_SHADE_NUM 0 /* shade when finished lanes / live lanes >= NUM / DEN (0 = as soon as any lane finished) */
@@ -483,11 +489,41 @@ PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_
     }
 }
 
-template <bool COUNT, int STACK>
+// A ray with an infinite direction reciprocal walks the reference's binary tree with the exact
+// select-form box test; every other ray walks the four-wide tree (see walk_slice).
+template <bool WIDE>
+PT_DEV bool ray_is_exact(f3 d) {
+    const float inf = __builtin_inff();
+    return !WIDE || __builtin_fabsf(1.0f / d.x) == inf || __builtin_fabsf(1.0f / d.y) == inf || __builtin_fabsf(1.0f / d.z) == inf;
+}
+
+template <bool WIDE>
+PT_DEV void walk_begin(const KernelParams &P, f3 d, float t_init, Walk &w) {
+    w.ref = ray_is_exact<WIDE>(d) ? P.root : P.root4;
+    w.pleaf = 0;
+    w.sp = 0;
+    w.h.t = t_init;
+    w.h.u = w.h.v = 0.f;
+    w.h.face = -1;
+    w.h.material = 0;
+    w.h.early = false;
+    if (w.ref > kDone) { // the whole tree is one leaf
+        w.pleaf = w.ref;
+        w.ref = kDone;
+    }
+}
+
+template <bool COUNT, int STACK, bool WIDE>
 PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t *stack, Walk &w, Tally &n) {
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float inf = __builtin_inff();
-    const bool exact = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
+    const bool inf_rinv = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
+#ifdef PT_WIDE_NO_FALLBACK
+    const bool exact = !WIDE;
+#else
+    const bool exact = !WIDE || inf_rinv; // walks the binary tree
+#endif
+    constexpr int slice = WIDE ? PT_SLICE_WIDE : PT_SLICE;
     int steps = 0; // wave-uniform: every exit test below is a ballot or this counter
     for (;;) {
         unsigned long long ts0 = stamp<COUNT>();
@@ -497,7 +533,7 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
             unsigned long long m_step = __builtin_amdgcn_ballot_w64(stepping);
             unsigned long long m_blocked = __builtin_amdgcn_ballot_w64(blocked);
             int n_step = __builtin_popcountll(m_step), n_blocked = __builtin_popcountll(m_blocked);
-            if (n_step == 0 || steps >= PT_SLICE || (n_blocked != 0 && n_blocked >= (n_step >> PT_BLOCKED_SHIFT))) break;
+            if (n_step == 0 || steps >= slice || (n_blocked != 0 && n_blocked >= (n_step >> PT_BLOCKED_SHIFT))) break;
             steps++;
             if (COUNT) {
                 unsigned long long m_parked = __builtin_amdgcn_ballot_w64(w.ref == kDone && w.pleaf != 0);
@@ -509,32 +545,72 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
                 }
             }
             if (stepping) {
-                const float4 *np = (const float4 *)(P.nodes + w.ref);
-                float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 if (COUNT) n.inner++;
                 region_tick<COUNT>(n, kRegInner);
-                float t1, t2;
-                if (!exact) {
-                    t1 = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, w.h.t);
-                    t2 = slab_fast(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, w.h.t);
-                } else {
-                    t1 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, w.h.t);
-                    t2 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, w.h.t);
-                }
-                uint32_t c1 = __float_as_uint(q3.x), c2 = __float_as_uint(q3.y);
-                if (t2 < t1) {
-                    uint32_t tc = c1; c1 = c2; c2 = tc;
-                    float tt = t1; t1 = t2; t2 = tt;
-                }
                 uint32_t next;
-                if (t1 == kNoHit) {
-                    next = kDone;
-                    if (w.sp > 0) next = stack[(--w.sp) * kBlock];
+                if (WIDE && !exact) {
+                    // four-wide node (layout.h): four slab tests, nearest child next, the other hits
+                    // pushed farthest first
+                    const float4 *np = (const float4 *)(P.nodes4 + w.ref);
+                    float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], cr = np[6];
+                    float t0 = slab_fast(mk3(lx.x, ly.x, lz.x), mk3(hx.x, hy.x, hz.x), o, rinv, w.h.t);
+                    float t1 = slab_fast(mk3(lx.y, ly.y, lz.y), mk3(hx.y, hy.y, hz.y), o, rinv, w.h.t);
+                    float t2 = slab_fast(mk3(lx.z, ly.z, lz.z), mk3(hx.z, hy.z, hz.z), o, rinv, w.h.t);
+                    float t3 = slab_fast(mk3(lx.w, ly.w, lz.w), mk3(hx.w, hy.w, hz.w), o, rinv, w.h.t);
+                    uint32_t c0 = __float_as_uint(cr.x), c1 = __float_as_uint(cr.y), c2 = __float_as_uint(cr.z), c3 = __float_as_uint(cr.w);
+                    if (c2 == kDone) t2 = kNoHit; // a wide node has two to four children
+                    if (c3 == kDone) t3 = kNoHit;
+#define PT_CSWAP(ta, ca, tb, cb)            \
+    if (tb < ta) {                          \
+        float tt_ = ta; ta = tb; tb = tt_;  \
+        uint32_t cc_ = ca; ca = cb; cb = cc_; \
+    }
+                    PT_CSWAP(t0, c0, t1, c1)
+                    PT_CSWAP(t2, c2, t3, c3)
+                    PT_CSWAP(t0, c0, t2, c2)
+                    PT_CSWAP(t1, c1, t3, c3)
+                    PT_CSWAP(t1, c1, t2, c2)
+#undef PT_CSWAP
+                    if (t0 == kNoHit) {
+                        next = kDone;
+                        if (w.sp > 0) next = stack[(--w.sp) * kBlock];
+                    } else {
+                        next = c0;
+                        // hits sort before misses, so the pushed entries are a prefix of (c3, c2, c1) reversed;
+                        // slots above sp are free (the stack bound is checked at upload), write them all
+                        int h3 = t3 != kNoHit, h2 = t2 != kNoHit, h1 = t1 != kNoHit;
+                        stack[w.sp * kBlock] = h3 ? c3 : (h2 ? c2 : c1);
+                        stack[(w.sp + 1) * kBlock] = h3 ? c2 : c1;
+                        stack[(w.sp + 2) * kBlock] = c1;
+                        w.sp += h3 + h2 + h1;
+                    }
                 } else {
-                    next = c1;
-                    if (t2 != kNoHit) {
-                        if (w.sp < STACK) stack[w.sp * kBlock] = c2; // height is checked at upload; never overflows
-                        w.sp++;
+                    // the reference's binary tree; with an infinite reciprocal (a zero direction component) its
+                    // exact select-form test, where 0 * inf = NaN decides as in intersect_aabb
+                    const float4 *np = (const float4 *)(P.nodes + w.ref);
+                    float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    float t1, t2;
+                    if (!inf_rinv) {
+                        t1 = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, w.h.t);
+                        t2 = slab_fast(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, w.h.t);
+                    } else {
+                        t1 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, w.h.t);
+                        t2 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, w.h.t);
+                    }
+                    uint32_t c1 = __float_as_uint(q3.x), c2 = __float_as_uint(q3.y);
+                    if (t2 < t1) {
+                        uint32_t tc = c1; c1 = c2; c2 = tc;
+                        float tt = t1; t1 = t2; t2 = tt;
+                    }
+                    if (t1 == kNoHit) {
+                        next = kDone;
+                        if (w.sp > 0) next = stack[(--w.sp) * kBlock];
+                    } else {
+                        next = c1;
+                        if (t2 != kNoHit) {
+                            stack[w.sp * kBlock] = c2;
+                            w.sp++;
+                        }
                     }
                 }
                 if (next > kDone && w.pleaf == 0) { // a leaf and room to park it: keep descending
@@ -569,7 +645,7 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
         }
         region_time<COUNT>(n, kRegLeaf, ts1, stamp<COUNT>());
         bool more = w.ref < kDone;
-        if (steps >= PT_SLICE || __builtin_amdgcn_ballot_w64(more) == 0) break;
+        if (steps >= slice || __builtin_amdgcn_ballot_w64(more) == 0) break;
         (void)any_leaf;
     }
 }
@@ -1071,7 +1147,7 @@ PT_DEV void ring_get(const uint32_t *ring, uint32_t pos, uint32_t &q, Rng &g, f3
 // other in their own order (so every pixel's arithmetic is unchanged), but the 64 lanes stay busy
 // until the tile's last few samples instead of until each lane's own pixel is complete: with one
 // pixel per lane the slowest of 64 pixels took 1.27x the mean (21 % of all lane time idle).
-template <bool COUNT, int STACK, int ROWS>
+template <bool COUNT, int STACK, int ROWS, bool WIDE>
 PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned long long *counters) {
     static_assert(ROWS >= 8 && ROWS <= 16, "tile rows");
     constexpr int kPool = 8 * ROWS;
@@ -1195,22 +1271,11 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         if (active) region_tick<COUNT>(n, kRegLoop);
         unsigned long long tl0 = stamp<COUNT>();
         if (active && !walking) { // start the walk of the ray set up by the previous iteration
-            wk.ref = P.root;
-            wk.pleaf = 0;
-            wk.sp = 0;
-            wk.h.t = s.t_init;
-            wk.h.u = wk.h.v = 0.f;
-            wk.h.face = -1;
-            wk.h.material = 0;
-            wk.h.early = false;
-            if (wk.ref > kDone) { // the whole tree is one leaf
-                wk.pleaf = wk.ref;
-                wk.ref = kDone;
-            }
+            walk_begin<WIDE>(P, s.rd, s.t_init, wk);
             if (COUNT) n.walks++;
             walking = true;
         }
-        walk_slice<COUNT, STACK>(P, s.ro, s.rd, s.t_stop, stack, wk, n);
+        walk_slice<COUNT, STACK, WIDE>(P, s.ro, s.rd, s.t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
         const bool finished = active && wk.ref == kDone && wk.pleaf == 0;
 
@@ -1272,16 +1337,16 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
     }
 }
 
-template <bool COUNT, int STACK, int ROWS>
+template <bool COUNT, int STACK, int ROWS, bool WIDE>
 __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) render_kernel(KernelParams P, float *__restrict__ img, unsigned long long *counters) {
-    render_body<COUNT, STACK, ROWS>(P, img, counters);
+    render_body<COUNT, STACK, ROWS, WIDE>(P, img, counters);
 }
 
 // The same code under its own name, for the 1-sample launch that records tile costs before the first
 // batch of a scene (no image): profiles then show the batches and the probe as separate kernels.
-template <int STACK, int ROWS>
+template <int STACK, int ROWS, bool WIDE>
 __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) cost_probe_kernel(KernelParams P) {
-    render_body<false, STACK, ROWS>(P, nullptr, nullptr);
+    render_body<false, STACK, ROWS, WIDE>(P, nullptr, nullptr);
 }
 
 // First camera ray of every pixel: face id + distance (parity probe).

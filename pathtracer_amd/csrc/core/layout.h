@@ -40,6 +40,20 @@ struct alignas(16) GNode {
 };
 static_assert(sizeof(GNode) == 64, "GNode must be one 64-byte line");
 
+// Four-wide node for rays whose direction reciprocals are all finite: the reference's binary tree
+// with every second level folded away at upload (collapse of the child with the larger box first).
+// Skipping an inner node's own box test is exact for such rays: (b - o) * rinv is monotone in b, so a
+// ray that passes a child's slab test passes every enclosing box's test too. Children are stored
+// axis-major so the four slab tests run as packed float math.
+struct alignas(16) GNode4 {
+    float lo[3][4];
+    float hi[3][4];
+    uint32_t child[4]; // node index | leaf reference | kNoChild
+    uint32_t pad[4];
+};
+static_assert(sizeof(GNode4) == 128, "GNode4 is one 128-byte line");
+constexpr uint32_t kNoChild = 0x7FFFFFFFu; // == kDone in kernel.h: neither a node nor a leaf
+
 struct alignas(16) GTri {
     float v0[3], e1[3], e2[3];
     uint32_t face;
@@ -107,6 +121,9 @@ struct BakedBvh {
     std::vector<GTri> tris;
     uint32_t root = 0; // child reference of the root
     int height = 0;    // nodes on the longest root-to-leaf path
+    std::vector<GNode4> nodes4;
+    uint32_t root4 = 0;   // child reference of the wide root (a leaf reference when the tree is one leaf)
+    int stack4 = 0;       // most stack entries a wide walk can hold at once
 };
 
 // Converts the reference-format BVH. Returns "" or an error message.
@@ -188,6 +205,90 @@ inline std::string bake_bvh(const std::vector<GShade> &shade, const pt_bvh_node 
     height = h[0];
     out.height = height;
     return "";
+}
+
+// Folds the baked binary tree into four-wide nodes. Call after bake_bvh.
+inline void bake_bvh4(BakedBvh &b) {
+    b.nodes4.clear();
+    b.root4 = b.root;
+    b.stack4 = 0;
+    if (b.nodes.empty()) return; // single leaf
+    struct Box { float lo[3], hi[3]; uint32_t ref; };
+    auto area = [](const Box &x) {
+        float dx = x.hi[0] - x.lo[0], dy = x.hi[1] - x.lo[1], dz = x.hi[2] - x.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto children_of = [&](uint32_t node, Box out[2]) {
+        const GNode &g = b.nodes[node];
+        for (int a = 0; a < 3; a++) {
+            out[0].lo[a] = g.lmin[a]; out[0].hi[a] = g.lmax[a];
+            out[1].lo[a] = g.rmin[a]; out[1].hi[a] = g.rmax[a];
+        }
+        out[0].ref = g.left;
+        out[1].ref = g.right;
+    };
+    // wide node index of a binary inner node that becomes a wide node's root, assigned on demand
+    std::vector<uint32_t> wide_of(b.nodes.size(), 0xFFFFFFFFu);
+    std::vector<uint32_t> todo; // binary nodes whose wide node still has to be filled, in allocation order
+    auto wide_index = [&](uint32_t node) {
+        if (wide_of[node] == 0xFFFFFFFFu) {
+            wide_of[node] = (uint32_t)b.nodes4.size();
+            b.nodes4.emplace_back();
+            todo.push_back(node);
+        }
+        return wide_of[node];
+    };
+    b.root4 = wide_index(0);
+    std::vector<int> need; // stack entries a walk below wide node i may need, filled afterwards
+    for (size_t k = 0; k < todo.size(); k++) {
+        uint32_t node = todo[k];
+        Box c[4];
+        int count = 2;
+        children_of(node, c);
+        while (count < 4) { // open the inner child with the largest box
+            int best = -1;
+            float best_area = -1.f;
+            for (int i = 0; i < count; i++)
+                if (!(c[i].ref & kLeafBit) && area(c[i]) > best_area) {
+                    best = i;
+                    best_area = area(c[i]);
+                }
+            if (best < 0) break;
+            Box two[2];
+            children_of(c[best].ref, two);
+            // keep left-to-right order: the opened child's children take its place
+            for (int i = count; i > best + 1; i--) c[i] = c[i - 1];
+            c[best] = two[0];
+            c[best + 1] = two[1];
+            count++;
+        }
+        GNode4 w;
+        memset(&w, 0, sizeof(w));
+        for (int i = 0; i < 4; i++) {
+            const Box &src = c[i < count ? i : 0];
+            for (int a = 0; a < 3; a++) {
+                w.lo[a][i] = src.lo[a];
+                w.hi[a][i] = src.hi[a];
+            }
+            if (i >= count) w.child[i] = kNoChild;
+            else if (src.ref & kLeafBit) w.child[i] = src.ref;
+            else w.child[i] = wide_index(src.ref);
+        }
+        b.nodes4[wide_of[node]] = w;
+    }
+    // stack bound: children follow parents in allocation order, so one reverse sweep suffices
+    need.assign(b.nodes4.size(), 0);
+    for (size_t k = b.nodes4.size(); k-- > 0;) {
+        const GNode4 &w = b.nodes4[k];
+        int count = 0, deepest = 0;
+        for (int i = 0; i < 4; i++) {
+            if (w.child[i] == kNoChild) continue;
+            count++;
+            if (!(w.child[i] & kLeafBit) && need[w.child[i]] > deepest) deepest = need[w.child[i]];
+        }
+        need[k] = (count - 1) + deepest;
+    }
+    b.stack4 = need[b.root4];
 }
 
 inline void bake_shading(const pt_scene_desc &scene, std::vector<GShade> &shade, std::vector<GMaterial> &mats) {

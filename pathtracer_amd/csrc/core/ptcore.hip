@@ -130,12 +130,14 @@ struct pt_context {
     static constexpr int kEventRing = 64;
     hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
     uint64_t launches = 0;
+    hipEvent_t ev_tune[2] = {};
 
     // host copies needed across uploads
     std::vector<GShade> h_shade;
     std::vector<uint32_t> h_light_mult; // per face: times listed in the LST
 
     DeviceArray<GNode> nodes;
+    DeviceArray<GNode4> nodes4;
     DeviceArray<GTri> tris;
     DeviceArray<GShade> shade;
     DeviceArray<GMaterial> materials;
@@ -164,6 +166,9 @@ struct pt_context {
     bool have_scene = false, have_bvh = false, have_lst = false, have_cfg = false;
     uint32_t face_count = 0, light_count = 0;
     int bvh_height = 0;
+    int stack_need = 0;  // traversal stack entries a walk of the binary tree can need (height - 1)
+    int stack_need4 = 0; // ... of the four-wide tree (with its binary fallback): picks the 32/48/64-entry kernel
+    int walk_tree = 0;  // 0 = not chosen yet for this tree, 2 = binary, 4 = four-wide
     KernelParams P{};
 };
 
@@ -274,7 +279,7 @@ int render_queue(pt_context *ctx, float *img, hipStream_t st) {
         for (int k = 0; k < group; k++) {
             uint32_t blocks = (live + 63u) / 64u;
             uint32_t wgrid = blocks < (uint32_t)ctx->walk_grid ? blocks : (uint32_t)ctx->walk_grid;
-            if (ctx->bvh_height <= 33)
+            if (ctx->stack_need <= 32)
                 hipLaunchKernelGGL((queue_walk_kernel<32>), dim3(wgrid), dim3(64), 0, st, P, Q, cur);
             else
                 hipLaunchKernelGGL((queue_walk_kernel<64>), dim3(wgrid), dim3(64), 0, st, P, Q, cur);
@@ -291,36 +296,53 @@ int render_queue(pt_context *ctx, float *img, hipStream_t st) {
     return 0;
 }
 
+template <bool COUNT, int ROWS, bool WIDE>
+void launch_render_as(pt_context *ctx, dim3 grid, float *img, unsigned long long *counters, hipStream_t st) {
+    const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
+    if (need <= 32)
+        hipLaunchKernelGGL((render_kernel<COUNT, 32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
+    else if (need <= 48)
+        hipLaunchKernelGGL((render_kernel<COUNT, 48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
+    else
+        hipLaunchKernelGGL((render_kernel<COUNT, 64, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
+}
+
 template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned long long *counters, hipStream_t st) {
     uint32_t ntx, nty;
     render_tiles(ctx, &ntx, &nty);
-    dim3 grid(ntx * nty), block(kBlock);
+    dim3 grid(ntx * nty);
     ctx->P.tile_order = (ctx->order_valid && g_lpt) ? ctx->tile_order.ptr : nullptr;
     ctx->P.tile_cost = g_lpt ? ctx->tile_cost.ptr : nullptr;
-    const bool tall = ctx->bvh_height > 33;
+    const bool wide = ctx->walk_tree == 4;
     if (ctx->tile_rows == 16) {
-        if (!tall) hipLaunchKernelGGL((render_kernel<COUNT, 32, 16>), grid, block, 0, st, ctx->P, img, counters);
-        else hipLaunchKernelGGL((render_kernel<COUNT, 64, 16>), grid, block, 0, st, ctx->P, img, counters);
+        if (wide) launch_render_as<COUNT, 16, true>(ctx, grid, img, counters, st);
+        else launch_render_as<COUNT, 16, false>(ctx, grid, img, counters, st);
     } else {
-        if (!tall) hipLaunchKernelGGL((render_kernel<COUNT, 32, 8>), grid, block, 0, st, ctx->P, img, counters);
-        else hipLaunchKernelGGL((render_kernel<COUNT, 64, 8>), grid, block, 0, st, ctx->P, img, counters);
+        if (wide) launch_render_as<COUNT, 8, true>(ctx, grid, img, counters, st);
+        else launch_render_as<COUNT, 8, false>(ctx, grid, img, counters, st);
     }
 }
 
-// 1-sample launch without an image: records the tile costs (see pt_render_batch_into).
-void launch_probe(pt_context *ctx, hipStream_t st) {
+template <int ROWS, bool WIDE> void launch_probe_as(pt_context *ctx, dim3 grid, hipStream_t st) {
+    const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
+    if (need <= 32) hipLaunchKernelGGL((cost_probe_kernel<32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
+    else if (need <= 48) hipLaunchKernelGGL((cost_probe_kernel<48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
+    else hipLaunchKernelGGL((cost_probe_kernel<64, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
+}
+
+// Short launch without an image: records the tile costs (see pt_render_batch_into).
+void launch_probe(pt_context *ctx, hipStream_t st, bool wide) {
     uint32_t ntx, nty;
     render_tiles(ctx, &ntx, &nty);
-    dim3 grid(ntx * nty), block(kBlock);
+    dim3 grid(ntx * nty);
     ctx->P.tile_order = nullptr;
     ctx->P.tile_cost = ctx->tile_cost.ptr;
-    const bool tall = ctx->bvh_height > 33;
     if (ctx->tile_rows == 16) {
-        if (!tall) hipLaunchKernelGGL((cost_probe_kernel<32, 16>), grid, block, 0, st, ctx->P);
-        else hipLaunchKernelGGL((cost_probe_kernel<64, 16>), grid, block, 0, st, ctx->P);
+        if (wide) launch_probe_as<16, true>(ctx, grid, st);
+        else launch_probe_as<16, false>(ctx, grid, st);
     } else {
-        if (!tall) hipLaunchKernelGGL((cost_probe_kernel<32, 8>), grid, block, 0, st, ctx->P);
-        else hipLaunchKernelGGL((cost_probe_kernel<64, 8>), grid, block, 0, st, ctx->P);
+        if (wide) launch_probe_as<8, true>(ctx, grid, st);
+        else launch_probe_as<8, false>(ctx, grid, st);
     }
 }
 
@@ -339,6 +361,8 @@ extern "C" int pt_create(int device, pt_context **out) {
     ctx->device = device;
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ctx->ev_tune[0]));
+    HIP_TRY(hipEventCreate(&ctx->ev_tune[1]));
     for (int i = 0; i < pt_context::kEventRing; i++) {
         HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
         HIP_TRY(hipEventCreate(&ctx->ev_stop[i]));
@@ -359,6 +383,7 @@ extern "C" void pt_destroy(pt_context *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release();
+    ctx->nodes4.release();
     ctx->tris.release();
     ctx->shade.release();
     ctx->materials.release();
@@ -375,6 +400,8 @@ extern "C" void pt_destroy(pt_context *ctx) {
     ctx->tile_key.release();
     ctx->q_state.release(); ctx->q_hit.release(); ctx->q_list0.release(); ctx->q_list1.release(); ctx->q_cnt.release();
     if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
+    for (int i = 0; i < 2; i++)
+        if (ctx->ev_tune[i]) (void)hipEventDestroy(ctx->ev_tune[i]);
     for (int i = 0; i < pt_context::kEventRing; i++) {
         if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
         if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
@@ -480,7 +507,22 @@ extern "C" int pt_bvh_upload(pt_context *ctx, const pt_bvh_node *nodes, uint32_t
     if (!err.empty()) return fail("pt_bvh_upload: %s", err.c_str());
     // the reference refuses trees taller than its 64-entry stack (bvh.cu:338-342)
     if (baked.height > 65) return fail("pt_bvh_upload: tree height %d exceeds the 64-entry traversal stack", baked.height);
+    bake_bvh4(baked);
+    // stack entries a walk may hold: height - 1 in the binary tree; in the four-wide one the folded bound
+    // (every sibling hit on the whole path) plus the 2 scratch slots the wide step writes above the top
+    int stack_need = baked.height - 1;
+    int stack_need4 = stack_need > baked.stack4 + 2 ? stack_need : baked.stack4 + 2;
+    if (stack_need > 64) return fail("pt_bvh_upload: a walk of this tree can need %d stack entries (64 available)", stack_need);
     if (ctx->nodes.upload(baked.nodes.data(), baked.nodes.size())) return 1;
+    if (ctx->nodes4.upload(baked.nodes4.data(), baked.nodes4.size())) return 1;
+    ctx->P.nodes4 = ctx->nodes4.ptr;
+    ctx->P.root4 = baked.root4;
+    ctx->stack_need = stack_need;
+    ctx->stack_need4 = stack_need4;
+    ctx->walk_tree = 0;
+    if (const char *e = getenv("PT_TREE")) ctx->walk_tree = strcmp(e, "wide") == 0 ? 4 : (strcmp(e, "binary") == 0 ? 2 : 0);
+    if (stack_need4 > 64) ctx->walk_tree = 2; // the folded tree could overflow the largest stack: binary only
+    ctx->order_valid = false;
     if (ctx->tris.upload(baked.tris.data(), baked.tris.size())) return 1;
     ctx->P.nodes = ctx->nodes.ptr;
     ctx->P.tris = ctx->tris.ptr;
@@ -629,11 +671,30 @@ extern "C" int pt_render_batch_into(pt_context *ctx, float *device_img, void *st
         if (render_queue(ctx, device_img, st)) return 1;
         HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));
     } else {
+        if (ctx->walk_tree == 0 && current_samples >= 8) {
+            // Which tree walks this scene faster depends on the scene (four-wide: half the node visits, but
+            // fewer lanes stepping together; measured both ways, -12 % .. +7 %). Both give the same hits, so
+            // time a 2-sample launch without an image on each and keep the faster. Blocks the host once per
+            // uploaded tree (about 10 ms).
+            float ms[2] = {0.f, 0.f};
+            ctx->P.current_samples = 2;
+            for (int k = 0; k < 2; k++) {
+                HIP_TRY(hipEventRecord(ctx->ev_tune[0], st));
+                launch_probe(ctx, st, k == 1);
+                HIP_TRY(hipEventRecord(ctx->ev_tune[1], st));
+                HIP_TRY(hipEventSynchronize(ctx->ev_tune[1]));
+                HIP_TRY(hipEventElapsedTime(&ms[k], ctx->ev_tune[0], ctx->ev_tune[1]));
+            }
+            ctx->walk_tree = ms[1] < ms[0] ? 4 : 2;
+            ctx->P.current_samples = current_samples;
+        } else if (ctx->walk_tree == 0) {
+            ctx->walk_tree = 2;
+        }
         if (g_lpt && !ctx->order_valid && current_samples >= 8) {
             // No costs recorded yet for this scene/resolution: a 1-sample launch that writes no pixel
             // (null image) records them, so that even the first batch is dispatched heaviest first.
             ctx->P.current_samples = 1;
-            launch_probe(ctx, st);
+            launch_probe(ctx, st, ctx->walk_tree == 4);
             launch_rank(ctx, st);
             ctx->P.current_samples = current_samples;
         }
@@ -749,9 +810,11 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
     return 0;
 }
 
+extern "C" int pt_walk_tree(pt_context *ctx) { return ctx ? ctx->walk_tree : 0; }
+
 extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
     if (!ctx) return 0;
-    return ctx->nodes.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
+    return ctx->nodes.bytes() + ctx->nodes4.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
            ctx->lst.bytes() + ctx->glights.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes() +
            ctx->tile_cost.bytes() + ctx->tile_key.bytes() + ctx->tile_order.bytes() +
            ctx->q_state.bytes() + ctx->q_hit.bytes() + ctx->q_list0.bytes() + ctx->q_list1.bytes() + ctx->q_cnt.bytes();

@@ -157,18 +157,7 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
                 ro = xyz(r0);
                 rd = xyz(r1);
                 t_stop = r1.w;
-                wk.ref = P.root;
-                wk.pleaf = 0;
-                wk.sp = 0;
-                wk.h.t = r0.w;
-                wk.h.u = wk.h.v = 0.f;
-                wk.h.face = -1;
-                wk.h.material = 0;
-                wk.h.early = false;
-                if (wk.ref > kDone) {
-                    wk.pleaf = wk.ref;
-                    wk.ref = kDone;
-                }
+                walk_begin<false>(P, rd, r0.w, wk);
             }
             res_next = res_next + (uint32_t)n_empty < res_end ? res_next + (uint32_t)n_empty : res_end;
         }
@@ -176,7 +165,7 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
             if (exhausted) break;
             continue;
         }
-        walk_slice<false, STACK>(P, ro, rd, t_stop, stack, wk, n);
+        walk_slice<false, STACK, false>(P, ro, rd, t_stop, stack, wk, n);
         if (slot >= 0 && wk.ref == kDone && wk.pleaf == 0) {
             if (t_stop != -1.0f) {
                 // shadow ray: visibility, then the bounce ray of the same vertex (same origin)
@@ -201,17 +190,7 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
                 rd = xyz(nx);
                 t_stop = -1.0f;
                 q_at(Q, qRay1, (uint32_t)slot) = pack(rd, -1.0f); // shade_kernel reads the direction it hit along
-                wk.ref = P.root;
-                wk.pleaf = 0;
-                wk.sp = 0;
-                wk.h.t = kNoHit;
-                wk.h.u = wk.h.v = 0.f;
-                wk.h.face = -1;
-                wk.h.early = false;
-                if (wk.ref > kDone) {
-                    wk.pleaf = wk.ref;
-                    wk.ref = kDone;
-                }
+                walk_begin<false>(P, rd, kNoHit, wk);
             } else {
                 float t = wk.h.face < 0 ? kNoHit : wk.h.t;
                 Q.hit[(uint32_t)slot] = make_float4(t, wk.h.u, wk.h.v, __int_as_float(wk.h.face));

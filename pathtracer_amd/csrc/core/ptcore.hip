@@ -301,6 +301,8 @@ void launch_render_as(pt_context *ctx, dim3 grid, float *img, unsigned long long
     const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
     if (need <= 32)
         hipLaunchKernelGGL((render_kernel<COUNT, 32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
+    else if (need <= 40)
+        hipLaunchKernelGGL((render_kernel<COUNT, 40, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
     else if (need <= 48)
         hipLaunchKernelGGL((render_kernel<COUNT, 48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
     else
@@ -326,6 +328,7 @@ template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned l
 template <int ROWS, bool WIDE> void launch_probe_as(pt_context *ctx, dim3 grid, hipStream_t st) {
     const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
     if (need <= 32) hipLaunchKernelGGL((cost_probe_kernel<32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
+    else if (need <= 40) hipLaunchKernelGGL((cost_probe_kernel<40, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
     else if (need <= 48) hipLaunchKernelGGL((cost_probe_kernel<48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
     else hipLaunchKernelGGL((cost_probe_kernel<64, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
 }

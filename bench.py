@@ -170,7 +170,7 @@ def main():
             "image_finite": finite, "image_mean": round(mean, 6),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "render_kernel<false,32,8>", "algorithmic_bytes_per_launch": int(abytes)},
+                         "kernel": "render_kernel<COUNT=false, STACK, ROWS=8, WIDE=%s>" % ("true" if tree == 4 else "false"), "algorithmic_bytes_per_launch": int(abytes)},
         }
         if not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)

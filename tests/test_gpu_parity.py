@@ -232,6 +232,34 @@ def test_single_leaf_tree_and_one_sample(renderer, scene_dir):
     assert gpu.max() > 0.3  # the emitter is in view
 
 
+def test_four_wide_tree_and_axis_parallel_rays(scene_dir, monkeypatch):
+    """PT_TREE=wide forces the four-wide tree (folded from the reference's at upload). A sun that
+    shines straight down the -z axis makes every one of its shadow rays axis-parallel (two infinite
+    direction reciprocals): those rays must take the binary tree and the reference's exact box test."""
+    w = scenes.GltfWriter()
+    grey = w.material("GREY", (0.6, 0.6, 0.6, 1), roughness=0.3)
+    w.node("Ground", mesh=w.mesh("Ground", [scenes.unit_plane(w, grey)]), scale=(3, 3, 1), translation=(0, 0, -1))
+    p, nrm, uv, idx = scenes.blob(10, 20, bump=0.3, seed=11)
+    w.node("Blob", mesh=w.mesh("Blob", [w.primitive(p, nrm, idx, grey, uv)]), scale=(0.5,) * 3, translation=(0.1, -0.2, -0.4))
+    w.node("Sun", light=w.light("directional", 4.0))  # no rotation: direction (0, 0, -1)
+    w.node("Camera", camera=w.camera(scenes.ROOM_CAMERA["yfov"]), rotation=scenes.ROOM_CAMERA["rotation"],
+           translation=scenes.ROOM_CAMERA["translation"])
+    b = util.load_bundle(w.write(scene_dir, "axis_sun"))
+    assert np.allclose(b.scene.lights["direction"][0], (0, 0, -1))
+    for tree, expect in (("wide", 4), ("binary", 2)):
+        monkeypatch.setenv("PT_TREE", tree)
+        r = core.Renderer(0)
+        try:
+            o = _setup(r, b, 88, 64, clear=(0.2, 0.2, 0.3))
+            gpu = r.render(13, 12, 6)
+            assert r.walk_tree() == expect
+            cpu = o.render(13, 12, 6)
+            _assert_images_match(gpu, cpu)
+            assert gpu.mean() > 0.05
+        finally:
+            r.close()
+
+
 def test_two_pixels_per_lane_tiles(cornell_like, monkeypatch):
     """Large images use 8x16 tiles whose 128 pixels are swapped between the 64 lanes every few
     samples (PT_TILE_ROWS=16 forces that kernel at a small size): ragged right and top edges, more

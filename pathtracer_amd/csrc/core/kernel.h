@@ -426,10 +426,10 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
 #define PT_SLICE 12
 #endif
 #ifndef PT_SLICE_WIDE
-#define PT_SLICE_WIDE 8
+#define PT_SLICE_WIDE 6
 #endif
 #ifndef PT_SHADE_NUM
-#define PT_SHADE_NUM 0 /* shade when finished lanes / live lanes >= NUM / DEN (0 = as soon as any lane finished) */
+#define PT_SHADE_NUM 1 /* shade when finished lanes / live lanes >= NUM / DEN (0 = as soon as any lane finished) */
 #endif
 #ifndef PT_SHADE_DEN
 #define PT_SHADE_DEN 4

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_internal.h"
@@ -432,31 +433,79 @@ inline float srgb_gamma(float c) {
 
 } // namespace
 
+namespace {
+
+// Row ranges on a few threads (PTH_BUILD_THREADS caps them, as for the BVH builder).
+template <typename F> void for_row_blocks(int height, F fn) {
+    unsigned want = std::thread::hardware_concurrency();
+    if (const char *e = getenv("PTH_BUILD_THREADS")) want = (unsigned)atoi(e);
+    if (want > 16) want = 16;
+    if (want < 1 || height < 64) want = 1;
+    if (want == 1) {
+        fn(0, 0, height);
+        return;
+    }
+    std::vector<std::thread> pool;
+    int per = (height + (int)want - 1) / (int)want;
+    for (unsigned t = 0; t < want; t++) {
+        int y0 = (int)t * per, y1 = y0 + per < height ? y0 + per : height;
+        if (y0 >= y1) break;
+        pool.emplace_back(fn, (int)t, y0, y1);
+    }
+    for (auto &th : pool) th.join();
+}
+
+} // namespace
+
+// image.cu:72-99. Both passes are per-pixel (the white point is a maximum, which no evaluation order
+// changes), so rows are split over threads; the bytes are those of the sequential loops.
 extern "C" int pth_tonemap_rgb8(const float *linear_rgb, int width, int height, uint8_t *rgb8) {
     const pt_vec3 *px = (const pt_vec3 *)linear_rgb;
-    float white = luminance(v3(1, 1, 1));
-    for (int y = 0; y < height; y++)
-        for (int x = 0; x < width; x++) {
-            pt_vec3 c = px[(size_t)y * (size_t)width + (size_t)x];
-            if (!std::isfinite(c.x) || !std::isfinite(c.y) || !std::isfinite(c.z)) {
-                set_error("pixel (%f, %f, %f) is not finite at (%d,%d)", c.x, c.y, c.z, x, y);
-                return 1;
+    float whites[16];
+    long long bad[16];
+    for (int t = 0; t < 16; t++) {
+        whites[t] = luminance(v3(1, 1, 1));
+        bad[t] = -1;
+    }
+    for_row_blocks(height, [&](int t, int y0, int y1) {
+        float white = whites[t];
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < width; x++) {
+                pt_vec3 c = px[(size_t)y * (size_t)width + (size_t)x];
+                if (!std::isfinite(c.x) || !std::isfinite(c.y) || !std::isfinite(c.z)) {
+                    if (bad[t] < 0) bad[t] = (long long)y * width + x;
+                    continue;
+                }
+                white = fmaxf(white, luminance(c));
             }
-            white = fmaxf(white, luminance(c));
-        }
-    for (int y = 0; y < height; y++)
-        for (int x = 0; x < width; x++) {
-            pt_vec3 c = px[(size_t)y * (size_t)width + (size_t)x];
-            // reinhard_extended_luminance + change_luminance
-            float l_old = luminance(c);
-            float numerator = l_old * (1.0f + (l_old / (white * white)));
-            float l_new = numerator / (1.0f + l_old);
-            c = scale(c, l_new / l_old);
-            size_t i = (size_t)(height - 1 - y) * (size_t)width + (size_t)x;
-            rgb8[3 * i + 0] = to_byte(srgb_gamma(c.x));
-            rgb8[3 * i + 1] = to_byte(srgb_gamma(c.y));
-            rgb8[3 * i + 2] = to_byte(srgb_gamma(c.z));
-        }
+        whites[t] = white;
+    });
+    long long first_bad = -1;
+    float white = luminance(v3(1, 1, 1));
+    for (int t = 0; t < 16; t++) {
+        if (bad[t] >= 0 && (first_bad < 0 || bad[t] < first_bad)) first_bad = bad[t];
+        white = fmaxf(white, whites[t]);
+    }
+    if (first_bad >= 0) {
+        pt_vec3 c = px[first_bad];
+        set_error("pixel (%f, %f, %f) is not finite at (%d,%d)", c.x, c.y, c.z, (int)(first_bad % width), (int)(first_bad / width));
+        return 1;
+    }
+    for_row_blocks(height, [&](int, int y0, int y1) {
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < width; x++) {
+                pt_vec3 c = px[(size_t)y * (size_t)width + (size_t)x];
+                // reinhard_extended_luminance + change_luminance
+                float l_old = luminance(c);
+                float numerator = l_old * (1.0f + (l_old / (white * white)));
+                float l_new = numerator / (1.0f + l_old);
+                c = scale(c, l_new / l_old);
+                size_t i = (size_t)(height - 1 - y) * (size_t)width + (size_t)x;
+                rgb8[3 * i + 0] = to_byte(srgb_gamma(c.x));
+                rgb8[3 * i + 1] = to_byte(srgb_gamma(c.y));
+                rgb8[3 * i + 2] = to_byte(srgb_gamma(c.z));
+            }
+    });
     return 0;
 }
 

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "ptcore.h"
@@ -115,32 +116,49 @@ int main(int argc, char *argv[]) {
     pth_log(3, "Kernel params <<<(%d), (64)>>> (one 8x8-pixel tile per wave64 workgroup)\n",
             ((cfg.resolution_x + 7) / 8) * ((cfg.resolution_y + 7) / 8));
 
+    // The reference copies the image back, tonemaps it and rewrites render.png after EVERY batch, inside
+    // the timed loop (main.cu:108-131). Same files, same log lines here, but that host work (about as long
+    // as a 50-spp launch at 1024^2) runs on a worker thread beside the next batch's kernel: the main thread
+    // reads batch k into one of two host buffers, waits until the worker is done with batch k-1, hands
+    // over, and launches batch k+1. Every "Rendered ..." line is still printed once its PNG is on disk.
+    std::vector<float> h_img2(pixels * 3);
+    float *buffers[2] = {h_img.data(), h_img2.data()};
     auto start = std::chrono::system_clock::now();
+    std::thread worker;
+    bool worker_failed = false;
     double kernel_seconds = 0;
-    int rendered = 0;
+    int rendered = 0, batch = 0;
     while (rendered < cfg.samples) {
         int current = cfg.samples_every_update < cfg.samples - rendered ? cfg.samples_every_update : cfg.samples - rendered;
         CORE_TRY(pt_render_batch(ctx, cfg.seed, rendered, current));
         kernel_seconds += pt_last_kernel_ms(ctx) / 1000.0;
-        CORE_TRY(pt_read_image(ctx, h_img.data()));
-        if (pth_write_image(h_img.data(), cfg.resolution_x, cfg.resolution_y, cfg.path_render)) {
-            pth_log(1, "%s\n", pth_last_error());
-            exit(EXIT_FAILURE);
-        }
+        float *buf = buffers[batch & 1];
+        CORE_TRY(pt_read_image(ctx, buf));
         rendered += current;
-
-        auto now = std::chrono::system_clock::now();
-        int elapsed_ms = (int)std::chrono::duration_cast<std::chrono::milliseconds>(now - start).count();
-        float elapsed = elapsed_ms / 1000.0f;
         cfg.seed++;
-        float ms_per_s = (float)cfg.resolution_x * cfg.resolution_y * rendered / (1000000.0 * elapsed);
-        float spp_per_s = rendered / elapsed;
-        pth_log(3, "Rendered %d out of %d S/px in %.1fs - %.2f S/px/s - %.2f MS/s\n", rendered, cfg.samples, elapsed,
-                spp_per_s, ms_per_s);
-        pth_log(3, "Kernel only: %.3fs - %.2f MS/s\n", kernel_seconds,
-                (double)pixels * rendered / (1e6 * (kernel_seconds > 0 ? kernel_seconds : 1e-9)));
-        pth_log(4, "Updated image: %s\n", cfg.path_render);
+        batch++;
+        if (worker.joinable()) worker.join();
+        if (worker_failed) exit(EXIT_FAILURE);
+        worker = std::thread([&, buf, rendered, kernel_seconds]() {
+            if (pth_write_image(buf, cfg.resolution_x, cfg.resolution_y, cfg.path_render)) {
+                pth_log(1, "%s\n", pth_last_error());
+                worker_failed = true;
+                return;
+            }
+            auto now = std::chrono::system_clock::now();
+            int elapsed_ms = (int)std::chrono::duration_cast<std::chrono::milliseconds>(now - start).count();
+            float elapsed = elapsed_ms / 1000.0f;
+            float ms_per_s = (float)cfg.resolution_x * cfg.resolution_y * rendered / (1000000.0 * elapsed);
+            float spp_per_s = rendered / elapsed;
+            pth_log(3, "Rendered %d out of %d S/px in %.1fs - %.2f S/px/s - %.2f MS/s\n", rendered, cfg.samples, elapsed,
+                    spp_per_s, ms_per_s);
+            pth_log(3, "Kernel only: %.3fs - %.2f MS/s\n", kernel_seconds,
+                    (double)pixels * rendered / (1e6 * (kernel_seconds > 0 ? kernel_seconds : 1e-9)));
+            pth_log(4, "Updated image: %s\n", cfg.path_render);
+        });
     }
+    if (worker.joinable()) worker.join();
+    if (worker_failed) exit(EXIT_FAILURE);
     // ########## DISPATCH #############
 
     pt_destroy(ctx);

@@ -371,6 +371,24 @@ def test_tonemap_reference_rules():
 
 # ---- oracle regression + flags + ABI surface ----------------------------------------------------------------
 
+def test_tonemap_threads_do_not_change_bytes(monkeypatch):
+    """The tonemapper splits rows over threads (the CLI runs it beside the next batch's kernel); its
+    white point is a maximum and every pixel is independent, so the bytes must equal the 1-thread run."""
+    rng = np.random.RandomState(4)
+    img = (rng.rand(150, 200, 3) ** 4 * 30).astype(np.float32)
+    img[10:20, 5:9] = 0.0  # black pixels take the explicit l_in == 0 rule
+    many = host.tonemap_rgb8(img)
+    monkeypatch.setenv("PTH_BUILD_THREADS", "1")
+    one = host.tonemap_rgb8(img)
+    assert np.array_equal(many, one) and many.std() > 10
+    bad = img.copy()
+    bad[140, 3, 1] = np.inf
+    bad[20, 7, 0] = np.nan
+    monkeypatch.delenv("PTH_BUILD_THREADS")
+    with pytest.raises(Exception, match=r"\(7,20\)"):
+        host.tonemap_rgb8(bad)
+
+
 def test_oracle_c1_golden():
     """BASELINE config 1 through the oracle equals the committed digests (guards the oracle)."""
     g = json.load(open(os.path.join(util.GOLDEN, "oracle_c1.json")))

@@ -493,8 +493,9 @@ PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_
 // select-form box test; every other ray walks the four-wide tree (see walk_slice).
 template <bool WIDE>
 PT_DEV bool ray_is_exact(f3 d) {
-    const float inf = __builtin_inff();
-    return !WIDE || __builtin_fabsf(1.0f / d.x) == inf || __builtin_fabsf(1.0f / d.y) == inf || __builtin_fabsf(1.0f / d.z) == inf;
+    // 1.0f / x rounds to infinity exactly when |x| <= 2^-128 (zero and the smallest subnormals)
+    const float tiny = 0x1p-128f;
+    return !WIDE || __builtin_fabsf(d.x) <= tiny || __builtin_fabsf(d.y) <= tiny || __builtin_fabsf(d.z) <= tiny;
 }
 
 template <bool WIDE>

@@ -318,6 +318,14 @@ PT_DEV float slab_fast(f3 bmin, f3 bmax, f3 o, f3 rinv, float limit) {
     return (tmax >= tmin && tmin < limit && tmax > 0) ? tmin : kNoHit;
 }
 
+// slab_fast after the plane distances have been formed (the wide step forms them two children at a time)
+typedef float v2f __attribute__((ext_vector_type(2)));
+PT_DEV float slab_planes(float ax, float ay, float az, float bx, float by, float bz, float limit) {
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    return (tmax >= tmin && tmin < limit && tmax > 0) ? tmin : kNoHit;
+}
+
 constexpr uint32_t kDone = 0x7FFFFFFFu; // not a node index (< 2^28 triangles => < 2^28 nodes)
 
 // bvh_intersect_iterative + the triangle half of intersect_face
@@ -554,10 +562,20 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
                     // pushed farthest first
                     const float4 *np = (const float4 *)(P.nodes4 + w.ref);
                     float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], cr = np[6];
-                    float t0 = slab_fast(mk3(lx.x, ly.x, lz.x), mk3(hx.x, hy.x, hz.x), o, rinv, w.h.t);
-                    float t1 = slab_fast(mk3(lx.y, ly.y, lz.y), mk3(hx.y, hy.y, hz.y), o, rinv, w.h.t);
-                    float t2 = slab_fast(mk3(lx.z, ly.z, lz.z), mk3(hx.z, hy.z, hz.z), o, rinv, w.h.t);
-                    float t3 = slab_fast(mk3(lx.w, ly.w, lz.w), mk3(hx.w, hy.w, hz.w), o, rinv, w.h.t);
+                    // (b - o) * rinv for the eight planes of two children at a time: packed fp32 math
+                    // (v_pk_add_f32 / v_pk_mul_f32 round like the scalar forms)
+                    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+                    const v2f rx = {rinv.x, rinv.x}, ry = {rinv.y, rinv.y}, rz = {rinv.z, rinv.z};
+                    v2f ax01 = (v2f{lx.x, lx.y} - ox) * rx, ax23 = (v2f{lx.z, lx.w} - ox) * rx;
+                    v2f ay01 = (v2f{ly.x, ly.y} - oy) * ry, ay23 = (v2f{ly.z, ly.w} - oy) * ry;
+                    v2f az01 = (v2f{lz.x, lz.y} - oz) * rz, az23 = (v2f{lz.z, lz.w} - oz) * rz;
+                    v2f bx01 = (v2f{hx.x, hx.y} - ox) * rx, bx23 = (v2f{hx.z, hx.w} - ox) * rx;
+                    v2f by01 = (v2f{hy.x, hy.y} - oy) * ry, by23 = (v2f{hy.z, hy.w} - oy) * ry;
+                    v2f bz01 = (v2f{hz.x, hz.y} - oz) * rz, bz23 = (v2f{hz.z, hz.w} - oz) * rz;
+                    float t0 = slab_planes(ax01.x, ay01.x, az01.x, bx01.x, by01.x, bz01.x, w.h.t);
+                    float t1 = slab_planes(ax01.y, ay01.y, az01.y, bx01.y, by01.y, bz01.y, w.h.t);
+                    float t2 = slab_planes(ax23.x, ay23.x, az23.x, bx23.x, by23.x, bz23.x, w.h.t);
+                    float t3 = slab_planes(ax23.y, ay23.y, az23.y, bx23.y, by23.y, bz23.y, w.h.t);
                     uint32_t c0 = __float_as_uint(cr.x), c1 = __float_as_uint(cr.y), c2 = __float_as_uint(cr.z), c3 = __float_as_uint(cr.w);
                     if (c2 == kDone) t2 = kNoHit; // a wide node has two to four children
                     if (c3 == kDone) t3 = kNoHit;

@@ -478,6 +478,49 @@ PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop
     }
 }
 
+// Two triangles at once: every product and sum of the two Moeller-Trumbore tests as one packed fp32
+// operation (same operations, same order and rounding as test_triangle; the reference's early
+// returns become the `ok` flags, and triangle 0 is committed before triangle 1 is compared, as in
+// the reference's loop over a leaf, bvh.cu:252-256).
+PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float4 b1, float4 c1, bool second, f3 o, f3 d,
+                               float t_stop, HitLite &h) {
+    const v2f dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+    const v2f v0x = {a0.x, a1.x}, v0y = {a0.y, a1.y}, v0z = {a0.z, a1.z};
+    const v2f e1x = {a0.w, a1.w}, e1y = {b0.x, b1.x}, e1z = {b0.y, b1.y};
+    const v2f e2x = {b0.z, b1.z}, e2y = {b0.w, b1.w}, e2z = {c0.x, c1.x};
+    // pvec = cross(d, e2)
+    v2f px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+    v2f det = e1x * px + (e1y * py + e1z * pz);
+    v2f inv_det = {1.0f / det.x, 1.0f / det.y};
+    v2f tx = v2f{o.x, o.x} - v0x, ty = v2f{o.y, o.y} - v0y, tz = v2f{o.z, o.z} - v0z;
+    v2f u = (tx * px + (ty * py + tz * pz)) * inv_det;
+    // qvec = cross(tvec, e1)
+    v2f qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+    v2f v = (dx * qx + (dy * qy + dz * qz)) * inv_det;
+    v2f t = (e2x * qx + (e2y * qy + e2z * qz)) * inv_det;
+    v2f uv = u + v;
+    bool ok0 = !(det.x > -PT_EPS_UP && det.x < PT_EPS_UP) && !(u.x <= -PT_EPS_UP || u.x > 1.0f) &&
+               !(v.x <= -PT_EPS_UP || uv.x > 1.0f) && t.x >= 0 && t.x < h.t;
+    if (ok0) {
+        h.t = t.x;
+        h.u = u.x;
+        h.v = v.x;
+        h.face = (int32_t)__float_as_uint(c0.y);
+        h.material = __float_as_uint(c0.z);
+        if (t.x <= t_stop) h.early = true;
+    }
+    bool ok1 = second && !(det.y > -PT_EPS_UP && det.y < PT_EPS_UP) && !(u.y <= -PT_EPS_UP || u.y > 1.0f) &&
+               !(v.y <= -PT_EPS_UP || uv.y > 1.0f) && t.y >= 0 && t.y < h.t;
+    if (ok1) {
+        h.t = t.y;
+        h.u = u.y;
+        h.v = v.y;
+        h.face = (int32_t)__float_as_uint(c1.y);
+        h.material = __float_as_uint(c1.z);
+        if (t.y <= t_stop) h.early = true;
+    }
+}
+
 // Leaves of the reference builder hold one or two faces (src/bvh.cu:143): both records are
 // fetched before either is tested so the second fetch does not wait for the first test.
 template <bool COUNT>
@@ -489,8 +532,7 @@ PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_
     float4 a0 = tp[0], b0 = tp[1], c0 = tp[2];
     float4 a1 = tp[second + 0], b1 = tp[second + 1], c1 = tp[second + 2];
     if (COUNT) n.tris += count;
-    test_triangle(a0, b0, c0, o, d, t_stop, h);
-    if (count > 1) test_triangle(a1, b1, c1, o, d, t_stop, h);
+    test_triangle_pair(a0, b0, c0, a1, b1, c1, count > 1, o, d, t_stop, h);
     for (uint32_t k = 2; k < count; k++) {
         const float4 *tq = (const float4 *)(P.tris + first + k);
         test_triangle(tq[0], tq[1], tq[2], o, d, t_stop, h);

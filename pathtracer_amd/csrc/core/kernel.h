@@ -724,12 +724,10 @@ PT_DEV float g1_schlick_ggx(float n_dot_v, float roughness) {
     return n_dot_v / (n_dot_v * (1.0f - k) + k);
 }
 
-#ifdef PT_INLINE_BRDF
-PT_DEV
-#else
-__device__ __noinline__
-#endif
-f3 brdf_eval(Brdf b, f3 wo, f3 wi) {
+// BRDF::eval for one direction, as the reference writes it. The kernel evaluates the two directions of
+// a vertex together (brdf_eval_pair below, element for element the same operations); this form is
+// kept as the statement of what each element computes.
+PT_DEV f3 brdf_eval(Brdf b, f3 wo, f3 wi) {
     float cos_theta_wi = max_gl(wi.z, 0.0f);
     f3 l = wi, v = wo;
     f3 h = normalize(l + v);
@@ -747,6 +745,59 @@ f3 brdf_eval(Brdf b, f3 wo, f3 wi) {
     f3 f_spec = ((F * D) * G) / (4.0f * n_dot_v * n_dot_l);
     f3 f_diff = ((b.baseColor * (mk3(1, 1, 1) - F)) * (float)(1.0 - (double)b.metallic)) * PT_1_PI_F;
     return (f_diff + f_spec) * cos_theta_wi;
+}
+
+struct BrdfPair {
+    f3 first, second;
+};
+
+// brdf_eval for two incident directions of one vertex (the light sample and the BSDF sample) at once:
+// what depends on the direction runs as packed fp32 pairs, what does not (F0, G1 of the outgoing
+// direction, the alpha terms) once. Every element sees the operations of brdf_eval in its order.
+#ifdef PT_INLINE_BRDF
+PT_DEV
+#else
+__device__ __noinline__
+#endif
+BrdfPair brdf_eval_pair(Brdf b, f3 wo, f3 wi0, f3 wi1) {
+    const v2f lx = {wi0.x, wi1.x}, ly = {wi0.y, wi1.y}, lz = {wi0.z, wi1.z};
+    const v2f cos_theta_wi = {max_gl(wi0.z, 0.0f), max_gl(wi1.z, 0.0f)};
+    const f3 v = wo;
+    // h = normalize(l + v)
+    v2f sx = lx + v2f{v.x, v.x}, sy = ly + v2f{v.y, v.y}, sz = lz + v2f{v.z, v.z};
+    v2f len2 = sx * sx + (sy * sy + sz * sz);
+    v2f inv_len = {rcp_exact(__builtin_sqrtf(len2.x)), rcp_exact(__builtin_sqrtf(len2.y))};
+    v2f hx = sx * inv_len, hy = sy * inv_len, hz = sz * inv_len;
+    float f0d = (float)(0.16 * (double)b.specular * (double)b.specular);
+    f3 F0_diel = mk3(1, 1, 1) * f0d;
+    f3 F0 = (b.baseColor * b.metallic) + (F0_diel * (1 - b.metallic));
+    v2f x = v2f{1.0f, 1.0f} - (v2f{v.x, v.x} * hx + (v2f{v.y, v.y} * hy + v2f{v.z, v.z} * hz));
+    f3 one_minus_F0 = mk3(1, 1, 1) - F0;
+    v2f Fx = v2f{F0.x, F0.x} + (((((v2f{one_minus_F0.x, one_minus_F0.x} * x) * x) * x) * x) * x);
+    v2f Fy = v2f{F0.y, F0.y} + (((((v2f{one_minus_F0.y, one_minus_F0.y} * x) * x) * x) * x) * x);
+    v2f Fz = v2f{F0.z, F0.z} + (((((v2f{one_minus_F0.z, one_minus_F0.z} * x) * x) * x) * x) * x);
+    float alpha = b.roughness * b.roughness;
+    float a2 = alpha * alpha, a2m1 = alpha * alpha - 1.0f;
+    v2f bb = hz * hz * v2f{a2m1, a2m1} + v2f{1.0f, 1.0f};
+    v2f denom = v2f{PT_PI_F, PT_PI_F} * bb * bb;
+    v2f D = {a2 / denom.x, a2 / denom.y};
+    float g1v = g1_schlick_ggx(v.z, b.roughness);
+    v2f G = v2f{g1_schlick_ggx(wi0.z, b.roughness), g1_schlick_ggx(wi1.z, b.roughness)} * v2f{g1v, g1v};
+    float n_dot_v = max_gl(v.z, 0.001f);
+    v2f n_dot_l = {max_gl(wi0.z, 0.001f), max_gl(wi1.z, 0.001f)};
+    v2f four_nn = v2f{4.0f * n_dot_v, 4.0f * n_dot_v} * n_dot_l;
+    v2f inv_four_nn = {rcp_exact(four_nn.x), rcp_exact(four_nn.y)};
+    v2f spx = ((Fx * D) * G) * inv_four_nn, spy = ((Fy * D) * G) * inv_four_nn, spz = ((Fz * D) * G) * inv_four_nn;
+    float dielectric = (float)(1.0 - (double)b.metallic);
+    const v2f one = {1.0f, 1.0f}, dd = {dielectric, dielectric}, ipi = {PT_1_PI_F, PT_1_PI_F};
+    v2f dfx = ((v2f{b.baseColor.x, b.baseColor.x} * (one - Fx)) * dd) * ipi;
+    v2f dfy = ((v2f{b.baseColor.y, b.baseColor.y} * (one - Fy)) * dd) * ipi;
+    v2f dfz = ((v2f{b.baseColor.z, b.baseColor.z} * (one - Fz)) * dd) * ipi;
+    v2f rx = (dfx + spx) * cos_theta_wi, ry = (dfy + spy) * cos_theta_wi, rz = (dfz + spz) * cos_theta_wi;
+    BrdfPair out;
+    out.first = mk3(rx.x, ry.x, rz.x);
+    out.second = mk3(rx.y, ry.y, rz.y);
+    return out;
 }
 
 PT_DEV float brdf_pdf() { return 1.0f / (2 * PT_PI_F); }
@@ -1036,7 +1087,8 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
 
                 // ---- sample_light_source (renderer.cu:164-249), everything but the visibility walk ----
                 bool shadow = false;
-                f3 nee_dir = mk3(0, 0, 0);
+                f3 nee_dir = mk3(0, 0, 0), l_ts = mk3(0, 0, 1), nee_radiance = mk3(0, 0, 0);
+                float nee_p = 1.0f;
                 float s_init = kNoHit, s_stop = -1.0f;
                 if (P.lst_count != 0) {
                     int node_index = (int)((float)P.lst_count * rng_uniform(s.rng));
@@ -1096,12 +1148,9 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                         }
                     }
                     if (can_see && p_lss > 0) {
-                        f3 l_ts = tbn_t_mul(vx, nee_dir);
-                        float p_brdf = brdf_pdf();
-                        f3 f_cos = brdf_eval(vx.brdf, vx.wo_ts, l_ts);
-                        f3 direct = f_cos * radiance;
-                        float weight = p_lss / (p_lss + p_brdf);
-                        s.direct_c = ((weight / p_lss) * s.thr) * direct;
+                        l_ts = tbn_t_mul(vx, nee_dir);
+                        nee_radiance = radiance;
+                        nee_p = p_lss;
                         shadow = true;
                     } else {
                         if (COUNT) n.rays++; // the reference still traced this shadow ray
@@ -1118,7 +1167,17 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                 } while (dot(r, r) > 1);
                 f3 wi = normalize(r);
                 wi.z = __builtin_fabsf(wi.z);
-                s.f_cos_next = brdf_eval(vx.brdf, vx.wo_ts, wi);
+                // both BRDF evaluations of the vertex together (the light's, renderer.cu:338-341, is only used
+                // when there is a shadow ray to trace)
+                const BrdfPair f_pair = brdf_eval_pair(vx.brdf, vx.wo_ts, l_ts, wi);
+                const f3 f_cos = f_pair.first;
+                s.f_cos_next = f_pair.second;
+                if (shadow) {
+                    float p_brdf = brdf_pdf();
+                    f3 direct = f_cos * nee_radiance;
+                    float weight = nee_p / (nee_p + p_brdf);
+                    s.direct_c = ((weight / nee_p) * s.thr) * direct;
+                }
                 if (COUNT) {
                     n.bounces++;
                     // the reference walks the BVH once per emissive LST node for the pdf

@@ -260,6 +260,25 @@ def test_four_wide_tree_and_axis_parallel_rays(scene_dir, monkeypatch):
             r.close()
 
 
+def test_full_size_stand_in_both_trees(scene_dir, monkeypatch):
+    """The bench scene itself (322 804 faces, tree height 28: the four-wide walk needs the 48-entry
+    stack instantiation), 256x256, 16 spp in two launches, on each tree."""
+    b = util.load_bundle(scenes.write_many_lights_standin(scene_dir, name="ml_full"))
+    assert len(b.scene.faces) == 322804
+    cpu = None
+    for tree in ("wide", "binary"):
+        monkeypatch.setenv("PT_TREE", tree)
+        r = core.Renderer(0)
+        try:
+            o = _setup(r, b, 256, 256)
+            gpu = r.render(42, 16, 8)
+            if cpu is None:
+                cpu = o.render(42, 16, 8)
+            _assert_images_match(gpu, cpu)
+        finally:
+            r.close()
+
+
 def test_two_pixels_per_lane_tiles(cornell_like, monkeypatch):
     """Large images use 8x16 tiles whose 128 pixels are swapped between the 64 lanes every few
     samples (PT_TILE_ROWS=16 forces that kernel at a small size): ragged right and top edges, more

@@ -83,11 +83,14 @@ int pt_lst_upload(pt_context *ctx, const pt_lst_node *nodes, uint32_t count);
  * leaves it uninitialised and relies on garbage * 0). */
 int pt_configure(pt_context *ctx, const pt_render_config *cfg);
 
-/* Launch order: the kernel renders one 8x8 pixel tile per wavefront. Every launch records how
- * long each tile kept its wave slot, and the next launch of the context dispatches the tiles
- * heaviest first (the reference's fixed 16x16 block order, src/main.cu:85-88, leaves the device
- * draining behind its slowest blocks). Pixels do not depend on the order. PT_LPT=0 in the
- * environment disables the reordering.
+/* Launch order: the kernel renders one tile per wavefront (8x8 pixels; 8x16 with two pixels per
+ * lane on images of 3 M pixels and more). Every launch records how long each tile kept its wave
+ * slot, and the next launch of the context dispatches the tiles heaviest first (the reference's
+ * fixed 16x16 block order, src/main.cu:85-88, leaves the device draining behind its slowest
+ * blocks). The first render launch after pt_bvh_upload first runs three short launches that write
+ * no pixel (two that time the binary and the four-wide form of the tree, see pt_walk_tree, and one
+ * that records tile costs) and blocks the host for about 10 ms while it reads the two timings.
+ * Pixels depend on none of this. PT_LPT=0 in the environment keeps the static order.
  *
  * render_kernel<<<grid, block>>>(d_img, d_bvh, d_scene, d_lst, cfg, prev, cur)
  * + cudaDeviceSynchronize — src/main.cu:104-106, src/renderer.cu:361-405.
@@ -97,8 +100,11 @@ int pt_render_batch(pt_context *ctx, int seed, int previous_samples, int current
 
 /* Same launch into a caller-owned DEVICE buffer of resolution_x*resolution_y*3
  * floats, on a caller stream (hipStream_t passed as void*, NULL = the
- * context's own stream), without synchronising. For callers that keep the
- * accumulator in their own device memory (multi-GPU reduce, graphs). */
+ * context's own stream), without synchronising (except in the first launch after
+ * pt_bvh_upload, see "Launch order" above). For callers that keep the
+ * accumulator in their own device memory (multi-GPU reduce). Launches of one
+ * context must stay on one stream: the tile order of a launch is written by the
+ * launch before it. */
 int pt_render_batch_into(pt_context *ctx, float *device_img, void *stream, int seed,
                          int previous_samples, int current_samples);
 

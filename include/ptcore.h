@@ -87,9 +87,9 @@ int pt_configure(pt_context *ctx, const pt_render_config *cfg);
  * lane on images of 3 M pixels and more). Every launch records how long each tile kept its wave
  * slot, and the next launch of the context dispatches the tiles heaviest first (the reference's
  * fixed 16x16 block order, src/main.cu:85-88, leaves the device draining behind its slowest
- * blocks). The first render launch after pt_bvh_upload first runs three short launches that write
- * no pixel (two that time the binary and the four-wide form of the tree, see pt_walk_tree, and one
- * that records tile costs) and blocks the host for about 10 ms while it reads the two timings.
+ * blocks). The first render launch after pt_bvh_upload first runs two short launches that write
+ * no pixel (they time the binary and the four-wide form of the tree, see pt_walk_tree, and record
+ * tile costs) and blocks the host for about 10 ms while it reads the two timings.
  * Pixels depend on none of this. PT_LPT=0 in the environment keeps the static order.
  *
  * render_kernel<<<grid, block>>>(d_img, d_bvh, d_scene, d_lst, cfg, prev, cur)

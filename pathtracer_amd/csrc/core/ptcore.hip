@@ -690,6 +690,7 @@ extern "C" int pt_render_batch_into(pt_context *ctx, float *device_img, void *st
             }
             ctx->walk_tree = ms[1] < ms[0] ? 4 : 2;
             ctx->P.current_samples = current_samples;
+            if (g_lpt && !ctx->order_valid) launch_rank(ctx, st); // the second probe's tile costs order the first batch
         } else if (ctx->walk_tree == 0) {
             ctx->walk_tree = 2;
         }

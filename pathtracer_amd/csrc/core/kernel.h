@@ -105,6 +105,7 @@ struct KernelParams {
     // launch order of the 8x8 tiles (heaviest first, from the previous launch's per-tile cost); both may be null
     const uint32_t *tile_order;
     uint32_t *tile_cost;
+    uint32_t *tile_rng; // [tiles][8]: RNG state (v0..v4, d) of each render tile's first pixel for this launch's seed
 };
 
 // ---- XORWOW ------------------------------------------------------------------------
@@ -147,21 +148,25 @@ PT_DEV void rng_matvec(const uint32_t *__restrict__ m, uint32_t v[5]) {
 }
 
 // curand_init(seed, subsequence, 0): scramble, then jump subsequence * 2^67.
-PT_DEV void rng_init(Rng &s, const uint32_t *__restrict__ jump, uint32_t seed_lo, uint32_t seed_hi, uint32_t subsequence) {
+// curand_init's seed scramble: the state of subsequence 0.
+PT_DEV void rng_seed(uint32_t v[5], uint32_t *d, uint32_t seed_lo, uint32_t seed_hi) {
     uint32_t s0 = seed_lo ^ 0xaad26b49u;
     uint32_t s1 = seed_hi ^ 0xf7dcefddu;
     uint32_t t0 = 1099087573u * s0;
     uint32_t t1 = 2591861531u * s1;
-    uint32_t v[5];
     v[0] = 123456789u + t0;
     v[1] = 362436069u ^ t0;
     v[2] = 521288629u + t1;
     v[3] = 88675123u ^ t1;
     v[4] = 5783321u + t0;
-    s.d = 6615241u + t1 + t0;
-    // Bits that are set in NO lane of the wave are skipped by a uniform branch.
+    *d = 6615241u + t1 + t0;
+}
+
+// Jump `count` subsequences (count * 2^67 steps) ahead: one matrix-vector product per set bit.
+// Bits that are set in NO lane of the wave are skipped by a uniform branch.
+PT_DEV void rng_jump(uint32_t v[5], const uint32_t *__restrict__ jump, uint32_t count) {
     for (int k = 0; k < 32; k++) {
-        bool mine = (subsequence >> k) & 1u;
+        bool mine = (count >> k) & 1u;
         if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
         uint32_t w[5] = {v[0], v[1], v[2], v[3], v[4]};
         rng_matvec(jump + (size_t)k * 160 * 8, w);
@@ -169,6 +174,25 @@ PT_DEV void rng_init(Rng &s, const uint32_t *__restrict__ jump, uint32_t seed_lo
             v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3]; v[4] = w[4];
         }
     }
+}
+
+// curand_init(seed, subsequence, 0): scramble, then jump subsequence * 2^67.
+PT_DEV void rng_init(Rng &s, const uint32_t *__restrict__ jump, uint32_t seed_lo, uint32_t seed_hi, uint32_t subsequence) {
+    uint32_t v[5];
+    rng_seed(v, &s.d, seed_lo, seed_hi);
+    rng_jump(v, jump, subsequence);
+    s.v0 = v[0]; s.v1 = v[1]; s.v2 = v[2]; s.v3 = v[3]; s.v4 = v[4];
+    s.extra = 0.f;
+    s.have_extra = 0;
+}
+
+// The same state reached in two jumps: `base` is the state of the tile's first pixel (tile_rng_kernel
+// computes it once per tile, where the render kernel's 64 lanes would each repeat the work), `delta`
+// the pixel's subsequence minus that pixel's. A^(a+b) = A^a * A^b, so the state is the same.
+PT_DEV void rng_init_from(Rng &s, const uint32_t *__restrict__ jump, const uint32_t *__restrict__ base, uint32_t delta) {
+    uint32_t v[5] = {base[0], base[1], base[2], base[3], base[4]};
+    s.d = base[5];
+    rng_jump(v, jump, delta);
     s.v0 = v[0]; s.v1 = v[1]; s.v2 = v[2]; s.v3 = v[3]; s.v4 = v[4];
     s.extra = 0.f;
     s.have_extra = 0;
@@ -1261,6 +1285,20 @@ PT_DEV void ring_get(const uint32_t *ring, uint32_t pos, uint32_t &q, Rng &g, f3
     sample = (int)ring[10 * kRing + pos];
 }
 
+// RNG state of every render tile's first pixel (tx * 8, ty * rows): one lane per tile.
+__global__ void __launch_bounds__(64) tile_rng_kernel(KernelParams P, uint32_t ntx, uint32_t nty, uint32_t rows) {
+    uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    bool valid = t < ntx * nty;
+    uint32_t tx = valid ? t % ntx : 0u, ty = valid ? t / ntx : 0u;
+    uint32_t v[5], d;
+    rng_seed(v, &d, P.seed_lo, P.seed_hi);
+    rng_jump(v, P.jump, valid ? ty * rows * (uint32_t)P.width + tx * 8u : 0u);
+    if (valid) {
+        uint32_t *out = P.tile_rng + (size_t)t * 8;
+        out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3]; out[4] = v[4]; out[5] = d;
+    }
+}
+
 // One wave renders a tile of kPool = 8 * ROWS pixels with 64 lanes. With ROWS = 16 a lane does NOT own a pixel for the whole
 // launch: after PT_SWAP_EVERY samples it swaps its pixel (RNG state, sum, count: 40 bytes) with the
 // one that has waited longest in the wave's LDS ring. A pixel's samples still run one after the
@@ -1303,7 +1341,7 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         pool_pixel<ROWS>(tx, ty, qq, &x, &y);
         bool inside = qq < (uint32_t)kPool && x < P.width && y < P.height && P.current_samples > 0;
         Rng g;
-        rng_init(g, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(y * P.width + x) : 0u);
+        rng_init_from(g, P.jump, P.tile_rng + (size_t)tile * 8, inside ? (uint32_t)((y - (int)(ty * (uint32_t)ROWS)) * P.width + (x - (int)(tx * 8u))) : 0u);
         if (r == 0) {
             if (inside) {
                 s.rng = g;

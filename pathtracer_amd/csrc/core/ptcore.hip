@@ -153,6 +153,7 @@ struct pt_context {
     DeviceArray<float> image;
     DeviceArray<unsigned long long> counters;
     DeviceArray<uint32_t> tile_cost, tile_key, tile_order; // one entry per tile (sized for 8x8 tiles)
+    DeviceArray<uint32_t> tile_rng;                        // 8 words per tile
     bool order_valid = false;                    // tile_order holds a permutation for this resolution
     int tile_rows = 8;                           // render_kernel's tile is 8 x tile_rows pixels (8 or 16)
 
@@ -296,6 +297,12 @@ int render_queue(pt_context *ctx, float *img, hipStream_t st) {
     return 0;
 }
 
+// Per-tile RNG base states for this launch's seed (ordered before the render launch on its stream).
+void launch_tile_rng(pt_context *ctx, uint32_t ntx, uint32_t nty, hipStream_t st) {
+    ctx->P.tile_rng = ctx->tile_rng.ptr;
+    hipLaunchKernelGGL(tile_rng_kernel, dim3((ntx * nty + 63u) / 64u), dim3(64), 0, st, ctx->P, ntx, nty, (uint32_t)ctx->tile_rows);
+}
+
 template <bool COUNT, int ROWS, bool WIDE>
 void launch_render_as(pt_context *ctx, dim3 grid, float *img, unsigned long long *counters, hipStream_t st) {
     const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
@@ -315,6 +322,7 @@ template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned l
     dim3 grid(ntx * nty);
     ctx->P.tile_order = (ctx->order_valid && g_lpt) ? ctx->tile_order.ptr : nullptr;
     ctx->P.tile_cost = g_lpt ? ctx->tile_cost.ptr : nullptr;
+    launch_tile_rng(ctx, ntx, nty, st);
     const bool wide = ctx->walk_tree == 4;
     if (ctx->tile_rows == 16) {
         if (wide) launch_render_as<COUNT, 16, true>(ctx, grid, img, counters, st);
@@ -340,6 +348,7 @@ void launch_probe(pt_context *ctx, hipStream_t st, bool wide) {
     dim3 grid(ntx * nty);
     ctx->P.tile_order = nullptr;
     ctx->P.tile_cost = ctx->tile_cost.ptr;
+    launch_tile_rng(ctx, ntx, nty, st);
     if (ctx->tile_rows == 16) {
         if (wide) launch_probe_as<16, true>(ctx, grid, st);
         else launch_probe_as<16, false>(ctx, grid, st);
@@ -401,6 +410,7 @@ extern "C" void pt_destroy(pt_context *ctx) {
     ctx->tile_cost.release();
     ctx->tile_order.release();
     ctx->tile_key.release();
+    ctx->tile_rng.release();
     ctx->q_state.release(); ctx->q_hit.release(); ctx->q_list0.release(); ctx->q_list1.release(); ctx->q_cnt.release();
     if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
     for (int i = 0; i < 2; i++)
@@ -643,6 +653,9 @@ extern "C" int pt_configure(pt_context *ctx, const pt_render_config *cfg) {
         ctx->tile_cost.release();
         ctx->tile_order.release();
         ctx->tile_key.release();
+        ctx->tile_rng.release();
+        ctx->tile_rng.count = tiles * 8;
+        HIP_TRY(hipMalloc((void **)&ctx->tile_rng.ptr, ctx->tile_rng.bytes()));
         ctx->tile_cost.count = ctx->tile_order.count = ctx->tile_key.count = tiles;
         HIP_TRY(hipMalloc((void **)&ctx->tile_cost.ptr, tiles * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **)&ctx->tile_key.ptr, tiles * sizeof(uint32_t)));
@@ -820,6 +833,6 @@ extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
     if (!ctx) return 0;
     return ctx->nodes.bytes() + ctx->nodes4.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
            ctx->lst.bytes() + ctx->glights.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes() +
-           ctx->tile_cost.bytes() + ctx->tile_key.bytes() + ctx->tile_order.bytes() +
+           ctx->tile_cost.bytes() + ctx->tile_key.bytes() + ctx->tile_order.bytes() + ctx->tile_rng.bytes() +
            ctx->q_state.bytes() + ctx->q_hit.bytes() + ctx->q_list0.bytes() + ctx->q_list1.bytes() + ctx->q_cnt.bytes();
 }

@@ -914,20 +914,23 @@ __global__ void __launch_bounds__(256) tile_key_kernel(const uint32_t *__restric
     key[t] = ((127u - cls) << 24) | w0;
 }
 
-__global__ void __launch_bounds__(256) tile_rank_kernel(const uint32_t *__restrict__ key, uint32_t *__restrict__ order, uint32_t n) {
-    __shared__ uint32_t chunk[256];
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t mine = i < n ? key[i] : 0xFFFFFFFFu;
-    uint32_t rank = 0;
-    for (uint32_t base = 0; base < n; base += 256u) {
-        uint32_t j = base + threadIdx.x;
-        chunk[threadIdx.x] = j < n ? key[j] : 0xFFFFFFFFu;
-        __syncthreads();
-#pragma unroll 16
-        for (uint32_t k = 0; k < 256u; k++) rank += chunk[k] < mine ? 1u : 0u;
-        __syncthreads();
-    }
-    if (i < n) order[rank] = i;
+// rank[i] += number of keys in this block's slice of the list that are smaller than key[i]. The slice is
+// read through a wave-uniform index (scalar loads), so the inner loop is one compare and one add per key;
+// gridDim.y slices run in parallel and meet in `rank` (zeroed by the host beforehand).
+__global__ void __launch_bounds__(64) tile_rank_kernel(const uint32_t *__restrict__ key, uint32_t *__restrict__ rank, uint32_t n) {
+    uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    uint32_t mine = i < n ? key[i] : 0u;
+    uint32_t per = (n + gridDim.y - 1u) / gridDim.y;
+    uint32_t j0 = blockIdx.y * per, j1 = j0 + per < n ? j0 + per : n;
+    uint32_t count = 0;
+#pragma unroll 8
+    for (uint32_t j = j0; j < j1; j++) count += key[j] < mine ? 1u : 0u;
+    if (i < n && count) atomicAdd(&rank[i], count);
+}
+
+__global__ void __launch_bounds__(64) tile_order_kernel(const uint32_t *__restrict__ rank, uint32_t *__restrict__ order, uint32_t n) {
+    uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i < n) order[rank[i]] = i;
 }
 
 PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {

@@ -219,7 +219,11 @@ void launch_rank(pt_context *ctx, hipStream_t st) {
     if (n >= (1u << 24)) return; // keys hold the static position in 24 bits; larger images keep the static order
     dim3 grid((n + 255u) / 256u), block(256);
     hipLaunchKernelGGL(tile_key_kernel, grid, block, 0, st, ctx->tile_cost.ptr, ctx->tile_key.ptr, n, ntx, nty);
-    hipLaunchKernelGGL(tile_rank_kernel, grid, block, 0, st, ctx->tile_key.ptr, ctx->tile_order.ptr, n);
+    // rank of every key among all keys (O(n^2) compares spread over n/64 x 16 blocks), then the scatter;
+    // tile_cost is free once the keys exist and holds the ranks
+    (void)hipMemsetAsync(ctx->tile_cost.ptr, 0, (size_t)n * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(tile_rank_kernel, dim3((n + 63u) / 64u, 16), dim3(64), 0, st, ctx->tile_key.ptr, ctx->tile_cost.ptr, n);
+    hipLaunchKernelGGL(tile_order_kernel, dim3((n + 63u) / 64u), dim3(64), 0, st, ctx->tile_cost.ptr, ctx->tile_order.ptr, n);
     ctx->order_valid = true;
 }
 

@@ -1288,10 +1288,13 @@ PT_DEV void ring_get(const uint32_t *ring, uint32_t pos, uint32_t &q, Rng &g, f3
     sample = (int)ring[10 * kRing + pos];
 }
 
-// RNG state of every render tile's first pixel (tx * 8, ty * rows): one lane per tile.
+// RNG state of every render tile's first pixel (tx * 8, ty * rows): one lane per tile, kTileRngLanes
+// tiles per wave (the work per wave is a chain of scalar row loads; more, emptier waves hide their
+// latency better than 256 full ones).
+constexpr uint32_t kTileRngLanes = 16;
 __global__ void __launch_bounds__(64) tile_rng_kernel(KernelParams P, uint32_t ntx, uint32_t nty, uint32_t rows) {
-    uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    bool valid = t < ntx * nty;
+    uint32_t t = blockIdx.x * kTileRngLanes + threadIdx.x;
+    bool valid = threadIdx.x < kTileRngLanes && t < ntx * nty;
     uint32_t tx = valid ? t % ntx : 0u, ty = valid ? t / ntx : 0u;
     uint32_t v[5], d;
     rng_seed(v, &d, P.seed_lo, P.seed_hi);

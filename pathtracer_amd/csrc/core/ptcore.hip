@@ -304,7 +304,8 @@ int render_queue(pt_context *ctx, float *img, hipStream_t st) {
 // Per-tile RNG base states for this launch's seed (ordered before the render launch on its stream).
 void launch_tile_rng(pt_context *ctx, uint32_t ntx, uint32_t nty, hipStream_t st) {
     ctx->P.tile_rng = ctx->tile_rng.ptr;
-    hipLaunchKernelGGL(tile_rng_kernel, dim3((ntx * nty + 63u) / 64u), dim3(64), 0, st, ctx->P, ntx, nty, (uint32_t)ctx->tile_rows);
+    hipLaunchKernelGGL(tile_rng_kernel, dim3((ntx * nty + kTileRngLanes - 1u) / kTileRngLanes), dim3(64), 0, st, ctx->P, ntx, nty,
+                       (uint32_t)ctx->tile_rows);
 }
 
 template <bool COUNT, int ROWS, bool WIDE>

@@ -1204,6 +1204,13 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                     f3 direct = f_cos * nee_radiance;
                     float weight = nee_p / (nee_p + p_brdf);
                     s.direct_c = ((weight / nee_p) * s.thr) * direct;
+                    // A light below the vertex's horizon (cos = 0) or a black throughput makes the term an
+                    // exact zero; light + 0 is light whatever the walk would find, so the walk is not taken.
+                    // (NaN and infinity are not zero: those vertices keep their walk and the reference's result.)
+                    if (s.direct_c.x == 0.0f && s.direct_c.y == 0.0f && s.direct_c.z == 0.0f) {
+                        shadow = false;
+                        if (COUNT) n.rays++; // the reference traced it
+                    }
                 }
                 if (COUNT) {
                     n.bounces++;

@@ -1,0 +1,53 @@
+"""Manual soak (not collected by pytest): random scenes / sizes / seeds / sample counts / launch splits,
+GPU image against the oracle, bit for bit. Usage: python3 tests/soak_gpu.py [n_cases] [seed]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import binding as ob  # noqa: E402
+from pathtracer_amd import core, scenes  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    d = tempfile.mkdtemp()
+    hdr = scenes.write_sky_hdr(d + "/sky.hdr")
+    makers = [
+        lambda k: (scenes.write_cornell_like(d, name=f"c{k}", detail=int(rng.randint(3, 14))), {}),
+        lambda k: (scenes.write_many_lights_standin(d, name=f"m{k}", rings=int(rng.randint(8, 90)), segments=int(rng.randint(8, 120))), {}),
+        lambda k: (scenes.write_dragon_standin(d, name=f"d{k}", rings=int(rng.randint(6, 70)), segments=int(rng.randint(6, 70))), {}),
+        lambda k: (scenes.write_glass_mirror_standin(d, name=f"g{k}", detail=int(rng.randint(4, 30))), {"clear_texture": hdr}),
+        lambda k: (scenes.write_textured_standin(d, name=f"t{k}", detail=int(rng.randint(4, 24))), {}),
+    ]
+    bad = 0
+    for k in range(n_cases):
+        path, kw = makers[rng.randint(len(makers))](k)
+        b = util.load_bundle(path, **kw)
+        w, h = int(rng.randint(9, 200)), int(rng.randint(9, 160))
+        spp, every = int(rng.randint(1, 24)), int(rng.randint(1, 12))
+        seed, exposure = int(rng.randint(-5, 10 ** 6)), float(rng.choice([0.0, 0.5, -1.0, 2.0]))
+        clear = tuple(float(x) for x in rng.choice([0.0, 0.3, 1.0], 3))
+        os.environ["PT_TREE"] = str(rng.choice(["wide", "binary"]))
+        os.environ["PT_TILE_ROWS"] = str(rng.choice(["8", "16"]))
+        r = core.Renderer(0)
+        r.upload(b.scene, b.bvh, b.lst)
+        r.configure(w, h, exposure, clear)
+        gpu = r.render(seed, spp, every)
+        cpu = ob.Oracle(b.scene, b.bvh, b.lst, w, h, exposure, clear).render(seed, spp, every)
+        diff = int((gpu != cpu).sum())
+        bad += diff != 0
+        print(f"case {k}: {os.path.basename(path)} faces {len(b.scene.faces)} {w}x{h} spp {spp}/{every} seed {seed} "
+              f"tree {os.environ['PT_TREE']} rows {os.environ['PT_TILE_ROWS']}: {'OK' if diff == 0 else f'{diff} floats differ'}",
+              flush=True)
+        r.close()
+    print("soak:", "all bit-identical" if bad == 0 else f"{bad} cases differ")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -21,6 +21,14 @@
 //    push/pop is one conflict-free ds_write_b32/ds_read_b32.
 //  * The camera basis and 2^exposure are per-launch constants computed on the
 //    host with the reference's operation order (renderer.cu:32-46, :393).
+//  * One handler per path vertex (vertex_handler): the direct term and the next
+//    bounce ray are finished before the shadow walk, which only answers "visible?".
+//  * The walk (walk_slice) is sliced and speculative, on the reference's tree folded
+//    four-wide at upload (layout.h) for rays with finite direction reciprocals.
+//  * Independent pairs of float operations are written on 2-vectors (packed fp32).
+//  * Tiles are dispatched heaviest first from the costs the previous launch recorded;
+//    large images give a wave two pixels per lane (render_body).
+// DESIGN.md §3 has the measurements behind each of these.
 //
 // Every float operation keeps the reference's association; build with
 // -ffp-contract=off. Doubles appear where the reference's unsuffixed literals

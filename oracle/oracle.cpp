@@ -616,7 +616,7 @@ V3 integrate_Li(Ctx &c, Ray ray) {
         M3 tbn_t = transposed(hit.tangentBasis);
         V3 wo_ts = tbn_t * -ray.r;
 
-        LightSample lss;
+        LightSample lss = {};
         sample_light_source(lss, c, hit);
         if (lss.p_lss > 0) {
             V3 l_ts = tbn_t * lss.dir;

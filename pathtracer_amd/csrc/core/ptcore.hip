@@ -367,16 +367,9 @@ void launch_probe(pt_context *ctx, hipStream_t st, bool wide) {
 
 extern "C" const char *pt_last_error(void) { return g_error; }
 
-extern "C" int pt_create(int device, pt_context **out) {
-    if (!out) return fail("pt_create: null output pointer");
-    *out = nullptr;
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev == 0) return fail("pt_create: no HIP device available (%s)", hipGetErrorString(e));
-    if (device < 0 || device >= ndev) return fail("pt_create: device %d out of range (0..%d)", device, ndev - 1);
-    pt_context *ctx = new pt_context();
-    ctx->device = device;
-    HIP_TRY(hipSetDevice(device));
+namespace {
+int create_resources(pt_context *ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ctx->ev_tune[0]));
     HIP_TRY(hipEventCreate(&ctx->ev_tune[1]));
@@ -389,6 +382,23 @@ extern "C" int pt_create(int device, pt_context **out) {
     unsigned long long zeros[32] = {0};
     if (ctx->counters.upload(zeros, 32)) return 1;
     ctx->P.jump = ctx->jump.ptr;
+    return 0;
+}
+} // namespace
+
+extern "C" int pt_create(int device, pt_context **out) {
+    if (!out) return fail("pt_create: null output pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail("pt_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail("pt_create: device %d out of range (0..%d)", device, ndev - 1);
+    pt_context *ctx = new pt_context();
+    ctx->device = device;
+    if (create_resources(ctx)) {
+        pt_destroy(ctx); // keeps the message of the call that failed
+        return 1;
+    }
     const char *kernel = getenv("PT_KERNEL");
     ctx->use_queue = kernel && strcmp(kernel, "queue") == 0;
     *out = ctx;
@@ -398,7 +408,7 @@ extern "C" int pt_create(int device, pt_context **out) {
 extern "C" void pt_destroy(pt_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release();
     ctx->nodes4.release();
     ctx->tris.release();
@@ -424,7 +434,7 @@ extern "C" void pt_destroy(pt_context *ctx) {
         if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
         if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
     }
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -451,6 +461,9 @@ extern "C" int pt_scene_upload(pt_context *ctx, const pt_scene_desc *scene) {
     if (scene->clearTexture >= (int32_t)scene->texture_count)
         return fail("pt_scene_upload: clearTexture %d of %u", scene->clearTexture, scene->texture_count);
 
+    // from here on the context holds no complete scene until this call has succeeded
+    ctx->have_scene = ctx->have_bvh = ctx->have_lst = false;
+    ctx->order_valid = false;
     std::vector<GMaterial> mats;
     bake_shading(*scene, ctx->h_shade, mats);
     ctx->h_light_mult.assign(scene->face_count, 0);
@@ -520,6 +533,7 @@ extern "C" int pt_bvh_upload(pt_context *ctx, const pt_bvh_node *nodes, uint32_t
     if (bind(ctx)) return 1;
     if (!ctx->have_scene) return fail("pt_bvh_upload: call pt_scene_upload first");
     if (!nodes || !indices) return fail("pt_bvh_upload: null argument");
+    ctx->have_bvh = false;
     BakedBvh baked;
     std::string err = bake_bvh(ctx->h_shade, nodes, node_count, indices, index_count, baked);
     if (!err.empty()) return fail("pt_bvh_upload: %s", err.c_str());
@@ -554,6 +568,7 @@ extern "C" int pt_lst_upload(pt_context *ctx, const pt_lst_node *nodes, uint32_t
     if (bind(ctx)) return 1;
     if (!ctx->have_scene) return fail("pt_lst_upload: call pt_scene_upload first");
     if (count && !nodes) return fail("pt_lst_upload: null argument");
+    ctx->have_lst = false;
     std::vector<uint32_t> mult(ctx->face_count, 0);
     for (uint32_t i = 0; i < count; i++) {
         if (nodes[i].type == PT_LST_SOURCE_FACE) {

@@ -343,6 +343,17 @@ def test_api_errors(renderer, cornell_like):
     r.configure(8, 8)
     with pytest.raises(core.CoreError):
         r.render_batch(1, 0, 0)
+    # an upload that fails leaves no usable tree behind: the next launch is refused, not run on stale data
+    r.render_batch(1, 0, 1)
+    bad = np.ascontiguousarray(cornell_like.bvh.nodes).copy()
+    bad["leftChild"][0] = len(bad) + 7
+    lib = r._lib
+    assert lib.pt_bvh_upload(r._ctx, bad.ctypes.data, len(bad), np.ascontiguousarray(cornell_like.bvh.indices).ctypes.data,
+                             len(cornell_like.bvh.indices)) != 0
+    with pytest.raises(core.CoreError, match="pt_bvh_upload"):
+        r.render_batch(1, 0, 1)
+    r.upload(cornell_like.scene, cornell_like.bvh, cornell_like.lst)
+    r.render_batch(1, 0, 1)
     r.close()
     with pytest.raises(core.CoreError):
         core.Renderer(99)

@@ -601,11 +601,7 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float inf = __builtin_inff();
     const bool inf_rinv = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
-#ifdef PT_WIDE_NO_FALLBACK
-    const bool exact = !WIDE;
-#else
     const bool exact = !WIDE || inf_rinv; // walks the binary tree
-#endif
     constexpr int slice = WIDE ? PT_SLICE_WIDE : PT_SLICE;
     int steps = 0; // wave-uniform: every exit test below is a ballot or this counter
     for (;;) {
@@ -717,11 +713,9 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
         unsigned long long ts1 = stamp<COUNT>();
         region_time<COUNT>(n, kRegInner, ts0, ts1);
         // leaf phase: parked leaves first, then the leaf a lane stands on (order of discovery)
-        bool any_leaf = false;
         for (;;) {
             bool has = w.pleaf != 0;
             if (__builtin_amdgcn_ballot_w64(has) == 0) break;
-            any_leaf = true;
             if (has) {
                 region_tick<COUNT>(n, kRegLeaf);
                 test_leaf<COUNT>(P, w.pleaf, o, d, t_stop, w.h, n);
@@ -739,7 +733,6 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
         region_time<COUNT>(n, kRegLeaf, ts1, stamp<COUNT>());
         bool more = w.ref < kDone;
         if (steps >= slice || __builtin_amdgcn_ballot_w64(more) == 0) break;
-        (void)any_leaf;
     }
 }
 
@@ -786,12 +779,8 @@ struct BrdfPair {
 // brdf_eval for two incident directions of one vertex (the light sample and the BSDF sample) at once:
 // what depends on the direction runs as packed fp32 pairs, what does not (F0, G1 of the outgoing
 // direction, the alpha terms) once. Every element sees the operations of brdf_eval in its order.
-#ifdef PT_INLINE_BRDF
-PT_DEV
-#else
-__device__ __noinline__
-#endif
-BrdfPair brdf_eval_pair(Brdf b, f3 wo, f3 wi0, f3 wi1) {
+// (kept out of line: inlined into the vertex handler it raises the register pressure there and costs 2 %)
+__device__ __noinline__ BrdfPair brdf_eval_pair(Brdf b, f3 wo, f3 wi0, f3 wi1) {
     const v2f lx = {wi0.x, wi1.x}, ly = {wi0.y, wi1.y}, lz = {wi0.z, wi1.z};
     const v2f cos_theta_wi = {max_gl(wi0.z, 0.0f), max_gl(wi1.z, 0.0f)};
     const f3 v = wo;

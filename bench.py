@@ -172,7 +172,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "render_kernel<COUNT=false, STACK, ROWS=8, WIDE=%s>" % ("true" if tree == 4 else "false"), "algorithmic_bytes_per_launch": int(abytes)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
             out["cpu_baseline"] = cpu_baseline(scene, bvh, lst, threads)
         print(json.dumps(out), flush=True)

@@ -2,6 +2,7 @@
 // gfx950 only; no CUDA-compat headers, no dual paths.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -119,6 +120,41 @@ H3 h_rgb_to_radiometric(H3 color, float intensity) {
     float photometric = intensity * m;
     float alpha = (float)((double)photometric / (683.0 * (double)hlum(cn)));
     return hscale(cn, alpha);
+}
+
+// Two faces on the same three points are hit at the same distance (bit for bit when the corners are in
+// the same order, within an ulp otherwise), and the reference keeps the one its traversal meets first.
+// Only the binary tree meets leaves in that order (kernel.h, walk_slice), so a scene with such faces is
+// walked on the binary tree. One 64-bit hash per face over its sorted corners, sorted; equal hashes are
+// compared for real.
+bool has_coincident_faces(const std::vector<GShade> &shade) {
+    struct Key {
+        uint64_t hash;
+        uint32_t face;
+    };
+    auto corners = [](const GShade &g, float out[9]) {
+        int order[3] = {0, 1, 2};
+        std::sort(order, order + 3, [&](int a, int b) { return memcmp(g.pos[a], g.pos[b], 12) < 0; });
+        for (int k = 0; k < 3; k++) memcpy(out + 3 * k, g.pos[order[k]], 12);
+    };
+    std::vector<Key> keys(shade.size());
+    for (size_t f = 0; f < shade.size(); f++) {
+        float c[9];
+        corners(shade[f], c);
+        uint64_t h = 1469598103934665603ull; // FNV-1a over the 36 bytes
+        const unsigned char *b = (const unsigned char *)c;
+        for (int i = 0; i < 36; i++) h = (h ^ b[i]) * 1099511628211ull;
+        keys[f] = {h, (uint32_t)f};
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.hash < b.hash; });
+    for (size_t i = 1; i < keys.size(); i++) {
+        if (keys[i].hash != keys[i - 1].hash) continue;
+        float a[9], b[9];
+        corners(shade[keys[i].face], a);
+        corners(shade[keys[i - 1].face], b);
+        if (memcmp(a, b, sizeof(a)) == 0) return true;
+    }
+    return false;
 }
 
 } // namespace
@@ -554,6 +590,7 @@ extern "C" int pt_bvh_upload(pt_context *ctx, const pt_bvh_node *nodes, uint32_t
     ctx->walk_tree = 0;
     if (const char *e = getenv("PT_TREE")) ctx->walk_tree = strcmp(e, "wide") == 0 ? 4 : (strcmp(e, "binary") == 0 ? 2 : 0);
     if (stack_need4 > 64) ctx->walk_tree = 2; // the folded tree could overflow the largest stack: binary only
+    if (ctx->walk_tree == 0 && has_coincident_faces(ctx->h_shade)) ctx->walk_tree = 2; // keeps the reference's tie order
     ctx->order_valid = false;
     if (ctx->tris.upload(baked.tris.data(), baked.tris.size())) return 1;
     ctx->P.nodes = ctx->nodes.ptr;

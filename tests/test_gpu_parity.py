@@ -279,6 +279,46 @@ def test_full_size_stand_in_both_trees(scene_dir, monkeypatch):
             r.close()
 
 
+def test_coincident_faces_keep_the_reference_tie_rule(cornell_like, monkeypatch):
+    """Every face three times, the copies in other colours: the copies are hit at exactly the same distance
+    and the reference keeps whichever its traversal tests first (strict `<`, intersect.cu:100). Leaves
+    hold two faces, so a triple spans two leaves and the order leaves are found in decides. The binary
+    tree finds them in the reference's order, the four-wide one sorts four children by distance, which need
+    not be that order (48 floats of this image differ with PT_TREE=wide). pt_bvh_upload looks for faces on
+    the same three points and walks such a scene on the binary tree: the image is the oracle's."""
+    sc0 = cornell_like.scene
+    f, m = sc0.faces.copy(), sc0.materials.copy()
+    copies, mats = [f], [m]
+    for k, tint in enumerate(((0.9, 0.1, 0.1), (0.1, 0.2, 0.9))):
+        fk, mk = f.copy(), m.copy()
+        fk["material"] += (k + 1) * len(m)
+        mk["baseColorFactor"][:, :3] = tint
+        copies.append(fk)
+        mats.append(mk)
+    n = len(f)
+    faces = np.empty(3 * n, f.dtype)
+    for i in range(3):  # which copy comes first rotates from face to face
+        sel = np.flatnonzero(np.arange(n) % 3 == i)
+        for j in range(3):
+            faces[3 * sel + j] = copies[(i + j) % 3][sel]
+    b = util.Bundle(host.Scene.from_arrays(sc0.vertices.copy(), faces, np.concatenate(mats), lights=sc0.lights.copy(),
+                                           camera=sc0.camera))
+    assert b.bvh.stats["number_leaves"] > n  # the triples are split over leaves
+    monkeypatch.delenv("PT_TREE", raising=False)
+    r = core.Renderer(0)
+    try:
+        o = _setup(r, b, 80, 64)
+        gpu = r.render(3, 8, 4)
+        assert r.walk_tree() == 2  # the upload saw the coincident faces: no tree timing, binary tree
+        cpu = o.render(3, 8, 4)
+        _assert_images_match(gpu, cpu)
+        # without coincident faces the first launch times both trees
+        _setup(r, cornell_like, 80, 64)
+        assert r.walk_tree() == 0
+    finally:
+        r.close()
+
+
 def test_two_pixels_per_lane_tiles(cornell_like, monkeypatch):
     """Large images use 8x16 tiles whose 128 pixels are swapped between the 64 lanes every few
     samples (PT_TILE_ROWS=16 forces that kernel at a small size): ragged right and top edges, more

@@ -1,0 +1,61 @@
+"""Manual check (not collected by pytest; about a minute): a BASELINE configuration at FULL size on the CPU
+oracle and on the GPU with each form of the tree, compared bit for bit. The suite compares at sizes the
+oracle finishes in seconds; this is the same comparison at the size the bench runs.
+
+  python3 tests/full_size_gpu.py [--scene many_lights|dragon|glass] [--res 1024] [--spp 50] [--batches 4] [--threads 16]
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import binding as ob  # noqa: E402
+from pathtracer_amd import core, scenes  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="many_lights")
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=50)
+    ap.add_argument("--batches", type=int, default=4)
+    ap.add_argument("--threads", type=int, default=16)
+    a = ap.parse_args()
+    gen = {"many_lights": scenes.write_many_lights_standin, "dragon": scenes.write_dragon_standin,
+           "glass": scenes.write_glass_mirror_standin}[a.scene]
+    clear = (1.0, 1.0, 1.0) if a.scene == "glass" else (0.0, 0.0, 0.0)
+    with tempfile.TemporaryDirectory() as d:
+        kw = {"clear_texture": scenes.write_sky_hdr(d + "/sky.hdr")} if a.scene == "glass" else {}
+        b = util.load_bundle(gen(d), **kw)
+    total = a.spp * a.batches
+    t0 = time.perf_counter()
+    cpu = ob.Oracle(b.scene, b.bvh, b.lst, a.res, a.res, 0.0, clear).render(42, total, a.spp, threads=a.threads)
+    dt = time.perf_counter() - t0
+    print(f"oracle: {a.scene} {a.res}x{a.res} {total} spp in {dt:.1f} s on {a.threads} threads "
+          f"({a.res * a.res * total / dt / 1e6:.2f} Msamples/s)", flush=True)
+    bad = 0
+    for tree in ("binary", "wide"):
+        os.environ["PT_TREE"] = tree
+        r = core.Renderer(0)
+        r.upload(b.scene, b.bvh, b.lst)
+        r.configure(a.res, a.res, 0.0, clear)
+        gpu = r.render(42, total, a.spp)
+        ms = r.last_kernel_ms()
+        r.close()
+        diff = gpu.view(np.uint32) != cpu.view(np.uint32)  # bits: NaN pixels of degenerate shading frames compare equal
+        n = int(diff.sum())
+        both = np.isfinite(gpu) & np.isfinite(cpu)
+        print(f"GPU {tree} tree ({ms:.1f} ms per launch): {n} of {diff.size} floats differ from the oracle in bits "
+              f"({int(diff.any(axis=2).sum())} pixels, max abs {float(np.abs(np.where(both, gpu - cpu, 0)).max()):.3e}); "
+              f"non-finite floats {int((~np.isfinite(gpu)).sum())} / {int((~np.isfinite(cpu)).sum())}", flush=True)
+        bad += n if tree == "binary" else 0
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

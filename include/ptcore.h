@@ -52,6 +52,9 @@ typedef struct {
      * with another one parked, [1] walk finished except for a parked leaf, [2] walk finished,
      * waiting for its result handler. (Lanes whose pixel is complete are 64*iters - lanes - these.) */
     uint64_t node_step_idle[3];
+    /* Walks of the four-wide tree that met two candidates within 2^-18 of each other and were repeated
+     * on the binary tree, whose order of leaves is the reference's (kernel.h, kCullSlack). */
+    uint64_t redone_walks;
 } pt_counters;
 
 const char *pt_last_error(void);

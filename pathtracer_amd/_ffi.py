@@ -80,7 +80,7 @@ class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
                 ("samples", "rays", "inner_visits", "tri_tests", "traversals", "shaded_hits", "bounces")] + \
                [("region_iters", C.c_uint64 * 6), ("region_lanes", C.c_uint64 * 6),
                 ("region_ticks", C.c_uint64 * 6), ("wave_ticks", C.c_uint64),
-                ("node_step_idle", C.c_uint64 * 3)]
+                ("node_step_idle", C.c_uint64 * 3), ("redone_walks", C.c_uint64)]
     REGIONS = ("loop", "inner", "leaf", "main", "nee", "bsdf")
 
     def as_dict(self):
@@ -88,6 +88,7 @@ class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
         d["lane_utilisation"] = {r: round(self.region_lanes[i] / (64.0 * self.region_iters[i]), 4) if self.region_iters[i] else None
                                  for i, r in enumerate(self.REGIONS)}
         d["wave_iterations"] = {r: int(self.region_iters[i]) for i, r in enumerate(self.REGIONS)}
+        d["redone_walks"] = int(self.redone_walks)
         if self.region_iters[1]:
             tot = 64.0 * self.region_iters[1]
             d["node_step_lanes"] = {"stepping": round(self.region_lanes[1] / tot, 4),

@@ -293,11 +293,28 @@ struct HitLite {
 // reference's own comparison is applied to its result.
 constexpr float kBand = 1e-4f;
 
+// A four-wide walk meets leaves in another order than the reference's binary traversal. While the closest
+// hit is closest by a margin that changes nothing. It can when two candidates lie within rounding of each
+// other: which is tested first decides an exact tie (strict "closer" rule), and a box test (other
+// arithmetic than the triangle test) may cull one of them in one order only. So a wide walk
+//  (a) culls boxes against the best distance times kCullSlack: every candidate within that of the best is tested;
+//  (b) notices when it tests a candidate within kNearUlps of the best so far;
+//  (c) then starts over on the binary tree, whose order is the reference's. The ray's t_init, negated,
+//      marks the walk as a binary one until the next ray (walk_slice); no lane state is added.
+// Box and triangle arithmetic agree to a few units of 2^-24, far inside both margins, so a wide walk that
+// noted nothing has a winner every other candidate loses to in any order.
+constexpr float kCullSlack = 1.0f + 0x1p-20f;
+constexpr uint32_t kNearUlps = 32u; // 2^-19 .. 2^-18 of the distance, twice the cull slack and more
+// t >= 0 and best > 0 are ordered like their bit patterns, so "within kNearUlps" is one subtraction and one
+// unsigned compare (the 1e30 of "no hit yet" is far from any distance)
+PT_DEV bool near_to(float t, float best) { return __float_as_uint(t) - __float_as_uint(best) + kNearUlps <= 2u * kNearUlps; }
+
 struct Tally {
     uint32_t samples, rays, inner, tris, walks, shaded, bounces;
     // wave-level occupancy of each code region (instrumented variant only): iterations executed by
     // the wave, and the sum of lanes that were active in them
     uint32_t w_iters[6], w_lanes[6];
+    uint32_t redone; // wide walks repeated on the binary tree (see kCullSlack)
     uint32_t w_idle[3]; // lanes that sat out a node step: blocked on two leaves | walk over but for a parked leaf | waiting for a handler
     unsigned long long *w_time; // LDS: shader-clock ticks per region, written by the wave's leader lane
 };
@@ -487,7 +504,8 @@ struct Walk {
 
 // Moeller-Trumbore on one pre-gathered triangle (src/intersect.cu:12-81, non-culling branch)
 // followed by the "closer" test of intersect_face (src/intersect.cu:100).
-PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop, HitLite &h) {
+template <bool NEAR>
+PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop, HitLite &h, bool &near) {
     f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
     f3 pvec = cross(d, e2);
     float det = dot(e1, pvec);
@@ -500,6 +518,7 @@ PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop
     float v = dot(d, qvec) * inv_det;
     if (v <= -PT_EPS_UP || (u + v) > 1.0f) return;
     float t = dot(e2, qvec) * inv_det;
+    if (NEAR && t >= 0 && near_to(t, h.t)) near = true;
     if (t >= 0 && t < h.t) {
         h.t = t;
         h.u = u;
@@ -514,8 +533,9 @@ PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop
 // operation (same operations, same order and rounding as test_triangle; the reference's early
 // returns become the `ok` flags, and triangle 0 is committed before triangle 1 is compared, as in
 // the reference's loop over a leaf, bvh.cu:252-256).
+template <bool NEAR>
 PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float4 b1, float4 c1, bool second, f3 o, f3 d,
-                               float t_stop, HitLite &h) {
+                               float t_stop, HitLite &h, bool &near) {
     const v2f dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
     const v2f v0x = {a0.x, a1.x}, v0y = {a0.y, a1.y}, v0z = {a0.z, a1.z};
     const v2f e1x = {a0.w, a1.w}, e1y = {b0.x, b1.x}, e1z = {b0.y, b1.y};
@@ -531,8 +551,10 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
     v2f v = (dx * qx + (dy * qy + dz * qz)) * inv_det;
     v2f t = (e2x * qx + (e2y * qy + e2z * qz)) * inv_det;
     v2f uv = u + v;
-    bool ok0 = !(det.x > -PT_EPS_UP && det.x < PT_EPS_UP) && !(u.x <= -PT_EPS_UP || u.x > 1.0f) &&
-               !(v.x <= -PT_EPS_UP || uv.x > 1.0f) && t.x >= 0 && t.x < h.t;
+    const bool in0 = !(det.x > -PT_EPS_UP && det.x < PT_EPS_UP) && !(u.x <= -PT_EPS_UP || u.x > 1.0f) &&
+                     !(v.x <= -PT_EPS_UP || uv.x > 1.0f) && t.x >= 0;
+    if (NEAR && in0 && near_to(t.x, h.t)) near = true;
+    bool ok0 = in0 && t.x < h.t;
     if (ok0) {
         h.t = t.x;
         h.u = u.x;
@@ -541,8 +563,10 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
         h.material = __float_as_uint(c0.z);
         if (t.x <= t_stop) h.early = true;
     }
-    bool ok1 = second && !(det.y > -PT_EPS_UP && det.y < PT_EPS_UP) && !(u.y <= -PT_EPS_UP || u.y > 1.0f) &&
-               !(v.y <= -PT_EPS_UP || uv.y > 1.0f) && t.y >= 0 && t.y < h.t;
+    const bool in1 = second && !(det.y > -PT_EPS_UP && det.y < PT_EPS_UP) && !(u.y <= -PT_EPS_UP || u.y > 1.0f) &&
+                     !(v.y <= -PT_EPS_UP || uv.y > 1.0f) && t.y >= 0;
+    if (NEAR && in1 && near_to(t.y, h.t)) near = true;
+    bool ok1 = in1 && t.y < h.t;
     if (ok1) {
         h.t = t.y;
         h.u = u.y;
@@ -555,8 +579,8 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
 
 // Leaves of the reference builder hold one or two faces (src/bvh.cu:143): both records are
 // fetched before either is tested so the second fetch does not wait for the first test.
-template <bool COUNT>
-PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_stop, HitLite &h, Tally &n) {
+template <bool COUNT, bool NEAR>
+PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_stop, HitLite &h, bool &near, Tally &n) {
     uint32_t first = leaf & 0x0FFFFFFFu;
     uint32_t count = ((leaf >> 28) & 7u) + 1;
     const float4 *tp = (const float4 *)(P.tris + first);
@@ -564,10 +588,10 @@ PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_
     float4 a0 = tp[0], b0 = tp[1], c0 = tp[2];
     float4 a1 = tp[second + 0], b1 = tp[second + 1], c1 = tp[second + 2];
     if (COUNT) n.tris += count;
-    test_triangle_pair(a0, b0, c0, a1, b1, c1, count > 1, o, d, t_stop, h);
+    test_triangle_pair<NEAR>(a0, b0, c0, a1, b1, c1, count > 1, o, d, t_stop, h, near);
     for (uint32_t k = 2; k < count; k++) {
         const float4 *tq = (const float4 *)(P.tris + first + k);
-        test_triangle(tq[0], tq[1], tq[2], o, d, t_stop, h);
+        test_triangle<NEAR>(tq[0], tq[1], tq[2], o, d, t_stop, h, near);
     }
 }
 
@@ -580,9 +604,8 @@ PT_DEV bool ray_is_exact(f3 d) {
     return !WIDE || __builtin_fabsf(d.x) <= tiny || __builtin_fabsf(d.y) <= tiny || __builtin_fabsf(d.z) <= tiny;
 }
 
-template <bool WIDE>
-PT_DEV void walk_begin(const KernelParams &P, f3 d, float t_init, Walk &w) {
-    w.ref = ray_is_exact<WIDE>(d) ? P.root : P.root4;
+PT_DEV void walk_reset(uint32_t root, float t_init, Walk &w) {
+    w.ref = root;
     w.pleaf = 0;
     w.sp = 0;
     w.h.t = t_init;
@@ -596,12 +619,18 @@ PT_DEV void walk_begin(const KernelParams &P, f3 d, float t_init, Walk &w) {
     }
 }
 
+template <bool WIDE>
+PT_DEV void walk_begin(const KernelParams &P, f3 d, float &t_init, Walk &w) {
+    t_init = __builtin_fabsf(t_init); // a walk sent back to the binary tree leaves it negated (walk_slice)
+    walk_reset(ray_is_exact<WIDE>(d) ? P.root : P.root4, t_init, w);
+}
+
 template <bool COUNT, int STACK, bool WIDE>
-PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t *stack, Walk &w, Tally &n) {
+PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float &t_init, float t_stop, uint32_t *stack, Walk &w, Tally &n) {
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float inf = __builtin_inff();
     const bool inf_rinv = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
-    const bool exact = !WIDE || inf_rinv; // walks the binary tree
+    const bool exact = !WIDE || inf_rinv || t_init < 0.0f; // walks the binary tree
     constexpr int slice = WIDE ? PT_SLICE_WIDE : PT_SLICE;
     int steps = 0; // wave-uniform: every exit test below is a ballot or this counter
     for (;;) {
@@ -642,10 +671,11 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
                     v2f bx01 = (v2f{hx.x, hx.y} - ox) * rx, bx23 = (v2f{hx.z, hx.w} - ox) * rx;
                     v2f by01 = (v2f{hy.x, hy.y} - oy) * ry, by23 = (v2f{hy.z, hy.w} - oy) * ry;
                     v2f bz01 = (v2f{hz.x, hz.y} - oz) * rz, bz23 = (v2f{hz.z, hz.w} - oz) * rz;
-                    float t0 = slab_planes(ax01.x, ay01.x, az01.x, bx01.x, by01.x, bz01.x, w.h.t);
-                    float t1 = slab_planes(ax01.y, ay01.y, az01.y, bx01.y, by01.y, bz01.y, w.h.t);
-                    float t2 = slab_planes(ax23.x, ay23.x, az23.x, bx23.x, by23.x, bz23.x, w.h.t);
-                    float t3 = slab_planes(ax23.y, ay23.y, az23.y, bx23.y, by23.y, bz23.y, w.h.t);
+                    const float lim = w.h.t * kCullSlack;
+                    float t0 = slab_planes(ax01.x, ay01.x, az01.x, bx01.x, by01.x, bz01.x, lim);
+                    float t1 = slab_planes(ax01.y, ay01.y, az01.y, bx01.y, by01.y, bz01.y, lim);
+                    float t2 = slab_planes(ax23.x, ay23.x, az23.x, bx23.x, by23.x, bz23.x, lim);
+                    float t3 = slab_planes(ax23.y, ay23.y, az23.y, bx23.y, by23.y, bz23.y, lim);
                     uint32_t c0 = __float_as_uint(cr.x), c1 = __float_as_uint(cr.y), c2 = __float_as_uint(cr.z), c3 = __float_as_uint(cr.w);
                     if (c2 == kDone) t2 = kNoHit; // a wide node has two to four children
                     if (c3 == kDone) t3 = kNoHit;
@@ -718,9 +748,18 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_stop, uint32_t
             if (__builtin_amdgcn_ballot_w64(has) == 0) break;
             if (has) {
                 region_tick<COUNT>(n, kRegLeaf);
-                test_leaf<COUNT>(P, w.pleaf, o, d, t_stop, w.h, n);
+                bool near = false;
+                test_leaf<COUNT, WIDE>(P, w.pleaf, o, d, t_stop, w.h, near, n);
                 w.pleaf = 0;
-                if (w.h.early) {
+                // see kCullSlack: start over on the binary tree. This slice's wide code must not step the lane
+                // again, so the slice ends here for the whole wave (steps is wave-uniform; the event is rare).
+                const bool redo = WIDE && near && !exact && t_init > 0.0f;
+                if (WIDE && __builtin_amdgcn_ballot_w64(redo) != 0) steps = slice;
+                if (redo) {
+                    walk_reset(P.root, t_init, w);
+                    t_init = -t_init;
+                    if (COUNT) n.redone++;
+                } else if (w.h.early) {
                     w.ref = kDone;
                     w.sp = 0;
                 } else if (w.ref > kDone) { // standing on the next leaf: park it, step off
@@ -1443,7 +1482,7 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
             if (COUNT) n.walks++;
             walking = true;
         }
-        walk_slice<COUNT, STACK, WIDE>(P, s.ro, s.rd, s.t_stop, stack, wk, n);
+        walk_slice<COUNT, STACK, WIDE>(P, s.ro, s.rd, s.t_init, s.t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
         const bool finished = active && wk.ref == kDone && wk.pleaf == 0;
 
@@ -1498,6 +1537,7 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         }
         for (int k = 0; k < 3; k++)
             if (n.w_idle[k]) atomicAdd(&counters[27 + k], (unsigned long long)n.w_idle[k]);
+        if (n.redone) atomicAdd(&counters[30], (unsigned long long)n.redone);
         if (lane == 0) {
             for (int k = 0; k < 6; k++) atomicAdd(&counters[20 + k], n.w_time[k]);
             atomicAdd(&counters[26], stamp<COUNT>() - t_kernel0); // wave lifetime

@@ -874,6 +874,7 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
     }
     out->wave_ticks = h[26];
     for (int k = 0; k < 3; k++) out->node_step_idle[k] = h[27 + k];
+    out->redone_walks = h[30];
     out->samples = h[0];
     out->rays = h[1];
     out->inner_visits = h[2];

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
             if (exhausted) break;
             continue;
         }
-        walk_slice<false, STACK, false>(P, ro, rd, t_stop, stack, wk, n);
+        { float t0 = kNoHit; walk_slice<false, STACK, false>(P, ro, rd, t0, t_stop, stack, wk, n); }
         if (slot >= 0 && wk.ref == kDone && wk.pleaf == 0) {
             if (t_stop != -1.0f) {
                 // shadow ray: visibility, then the bounce ray of the same vertex (same origin)
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
                 rd = xyz(nx);
                 t_stop = -1.0f;
                 q_at(Q, qRay1, (uint32_t)slot) = pack(rd, -1.0f); // shade_kernel reads the direction it hit along
-                walk_begin<false>(P, rd, kNoHit, wk);
+                { float t0 = kNoHit; walk_begin<false>(P, rd, t0, wk); }
             } else {
                 float t = wk.h.face < 0 ? kNoHit : wk.h.t;
                 Q.hit[(uint32_t)slot] = make_float4(t, wk.h.u, wk.h.v, __int_as_float(wk.h.face));

@@ -283,9 +283,9 @@ def test_coincident_faces_keep_the_reference_tie_rule(cornell_like, monkeypatch)
     """Every face three times, the copies in other colours: the copies are hit at exactly the same distance
     and the reference keeps whichever its traversal tests first (strict `<`, intersect.cu:100). Leaves
     hold two faces, so a triple spans two leaves and the order leaves are found in decides. The binary
-    tree finds them in the reference's order, the four-wide one sorts four children by distance, which need
-    not be that order (48 floats of this image differ with PT_TREE=wide). pt_bvh_upload looks for faces on
-    the same three points and walks such a scene on the binary tree: the image is the oracle's."""
+    tree finds them in the reference's order; the four-wide one sorts four children by distance, which need
+    not be that order. pt_bvh_upload looks for faces on the same three points and walks such a scene on the
+    binary tree: the image is the oracle's."""
     sc0 = cornell_like.scene
     f, m = sc0.faces.copy(), sc0.materials.copy()
     copies, mats = [f], [m]
@@ -315,6 +315,18 @@ def test_coincident_faces_keep_the_reference_tie_rule(cornell_like, monkeypatch)
         # without coincident faces the first launch times both trees
         _setup(r, cornell_like, 80, 64)
         assert r.walk_tree() == 0
+    finally:
+        r.close()
+    # Forced onto the four-wide tree, the walk notices candidates at (nearly) the same distance and repeats
+    # itself on the binary tree: slower on such a scene, the same image.
+    monkeypatch.setenv("PT_TREE", "wide")
+    r = core.Renderer(0)
+    try:
+        _setup(r, b, 80, 64)
+        gpu = r.render(3, 8, 4)
+        assert r.walk_tree() == 4
+        _assert_images_match(gpu, cpu)
+        assert r.count_batch(3, 4)["redone_walks"] > 1000
     finally:
         r.close()
 

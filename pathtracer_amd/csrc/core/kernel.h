@@ -24,7 +24,9 @@
 //  * One handler per path vertex (vertex_handler): the direct term and the next
 //    bounce ray are finished before the shadow walk, which only answers "visible?".
 //  * The walk (walk_slice) is sliced and speculative, on the reference's tree folded
-//    four-wide at upload (layout.h) for rays with finite direction reciprocals.
+//    four-wide at upload (layout.h) for rays with finite direction reciprocals; a wide walk
+//    that meets two candidates within rounding of each other starts over on the binary
+//    tree, whose order of leaves is the reference's (kCullSlack).
 //  * Independent pairs of float operations are written on 2-vectors (packed fp32).
 //  * Tiles are dispatched heaviest first from the costs the previous launch recorded;
 //    large images give a wave two pixels per lane (render_body).

@@ -64,7 +64,9 @@ def pmc_traffic():
     workload, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950). Counters cannot be read
     from inside this process, so the figure is the profiled one, not a live one."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_*.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_*.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])  # round, then kernel version
     for f in reversed(files):
         try:
             d = json.load(open(f)).get("derived", {})

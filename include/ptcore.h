@@ -145,9 +145,10 @@ float pt_kernel_ms(pt_context *ctx, int launches_back);
 /* Which form of the uploaded tree the render launches walk: 2 = the reference's binary tree, 4 = the
  * same tree folded four-wide at upload, 0 = not chosen yet. Both give the same hits; the first render
  * launch after pt_bvh_upload times a 2-sample launch on each and keeps the faster (PT_TREE=binary|wide
- * in the environment forces one). Exception: faces on the same three points are hit at the same
- * distance, the reference keeps the one its traversal meets first, and only the binary tree meets
- * leaves in that order; pt_bvh_upload looks for such faces and then answers 2 at once. */
+ * in the environment forces one). Only the binary tree meets leaves in the reference's order; a walk of
+ * the four-wide one that finds two candidates within rounding of each other starts over on the binary
+ * tree (pt_counters.redone_walks), so the choice never shows in a pixel. Faces on the same three points
+ * would make every ray through them do that: pt_bvh_upload looks for such faces and then answers 2 at once. */
 int pt_walk_tree(pt_context *ctx);
 
 /* Bytes of device memory held by the context (scene + BVH + LST + image). */

@@ -295,20 +295,25 @@ struct HitLite {
 // reference's own comparison is applied to its result.
 constexpr float kBand = 1e-4f;
 
-// A four-wide walk meets leaves in another order than the reference's binary traversal. While the closest
-// hit is closest by a margin that changes nothing. It can when two candidates lie within rounding of each
-// other: which is tested first decides an exact tie (strict "closer" rule), and a box test (other
-// arithmetic than the triangle test) may cull one of them in one order only. So a wide walk
-//  (a) culls boxes against the best distance times kCullSlack: every candidate within that of the best is tested;
+// The walks below are speculative: a lane parks a leaf and keeps descending, so it culls boxes against a
+// staler best distance than the reference, and a four-wide walk also meets leaves in another order than the
+// reference's binary traversal. While the closest hit is closest by a margin none of that matters. It does
+// when two candidates lie within rounding of each other: which is tested first decides an exact tie (strict
+// "closer" rule), and the box test (other arithmetic than the triangle test) may cull one of them against one
+// best distance and not against another. So a speculative walk
+//  (a) on the wide tree, culls boxes against the best distance times kCullSlack (on the binary tree its stale
+//      distance already culls less than the reference does): every candidate that close to the best is tested;
 //  (b) notices when it tests a candidate within kNearUlps of the best so far;
-//  (c) then starts over on the binary tree, whose order is the reference's. The ray's t_init, negated,
-//      marks the walk as a binary one until the next ray (walk_slice); no lane state is added.
-// Box and triangle arithmetic agree to a few units of 2^-24, far inside both margins, so a wide walk that
-// noted nothing has a winner every other candidate loses to in any order.
-constexpr float kCullSlack = 1.0f + 0x1p-20f;
-constexpr uint32_t kNearUlps = 32u; // 2^-19 .. 2^-18 of the distance, twice the cull slack and more
+//  (c) then starts over as a SEQUENTIAL walk of the binary tree: a leaf is tested before the walk goes on, which
+//      is the reference's loop (bvh.cu:239-286) step for step. The ray's t_init, negated, marks such a walk
+//      until the next ray (walk_slice); no lane state is added.
+// Box and triangle arithmetic agree to a few units of 2^-24, far inside both margins, so a speculative walk that
+// noticed nothing has a winner every other candidate loses to in any order and under any culling.
+constexpr float kCullSlack = 1.0f + 0x1p-13f;
+constexpr uint32_t kNearUlps = 4096u; // 2^-12 .. 2^-11 of the distance, twice the cull slack and more
 // t >= 0 and best > 0 are ordered like their bit patterns, so "within kNearUlps" is one subtraction and one
 // unsigned compare (the 1e30 of "no hit yet" is far from any distance)
+// (`best` must be a hit's distance, not the t_init a shadow walk starts from: callers test h.face >= 0)
 PT_DEV bool near_to(float t, float best) { return __float_as_uint(t) - __float_as_uint(best) + kNearUlps <= 2u * kNearUlps; }
 
 struct Tally {
@@ -520,7 +525,7 @@ PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop
     float v = dot(d, qvec) * inv_det;
     if (v <= -PT_EPS_UP || (u + v) > 1.0f) return;
     float t = dot(e2, qvec) * inv_det;
-    if (NEAR && t >= 0 && near_to(t, h.t)) near = true;
+    if (NEAR && t >= 0 && h.face >= 0 && near_to(t, h.t)) near = true;
     if (t >= 0 && t < h.t) {
         h.t = t;
         h.u = u;
@@ -555,7 +560,7 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
     v2f uv = u + v;
     const bool in0 = !(det.x > -PT_EPS_UP && det.x < PT_EPS_UP) && !(u.x <= -PT_EPS_UP || u.x > 1.0f) &&
                      !(v.x <= -PT_EPS_UP || uv.x > 1.0f) && t.x >= 0;
-    if (NEAR && in0 && near_to(t.x, h.t)) near = true;
+    if (NEAR && in0 && h.face >= 0 && near_to(t.x, h.t)) near = true;
     bool ok0 = in0 && t.x < h.t;
     if (ok0) {
         h.t = t.x;
@@ -567,7 +572,7 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
     }
     const bool in1 = second && !(det.y > -PT_EPS_UP && det.y < PT_EPS_UP) && !(u.y <= -PT_EPS_UP || u.y > 1.0f) &&
                      !(v.y <= -PT_EPS_UP || uv.y > 1.0f) && t.y >= 0;
-    if (NEAR && in1 && near_to(t.y, h.t)) near = true;
+    if (NEAR && in1 && h.face >= 0 && near_to(t.y, h.t)) near = true;
     bool ok1 = in1 && t.y < h.t;
     if (ok1) {
         h.t = t.y;
@@ -632,7 +637,8 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float &t_init, float t
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float inf = __builtin_inff();
     const bool inf_rinv = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
-    const bool exact = !WIDE || inf_rinv || t_init < 0.0f; // walks the binary tree
+    const bool seq = t_init < 0.0f;                  // sequential walk (see kCullSlack)
+    const bool exact = !WIDE || inf_rinv || seq;      // walks the binary tree
     constexpr int slice = WIDE ? PT_SLICE_WIDE : PT_SLICE;
     int steps = 0; // wave-uniform: every exit test below is a ballot or this counter
     for (;;) {
@@ -737,7 +743,7 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float &t_init, float t
                 if (next > kDone && w.pleaf == 0) { // a leaf and room to park it: keep descending
                     w.pleaf = next;
                     next = kDone;
-                    if (w.sp > 0) next = stack[(--w.sp) * kBlock];
+                    if (w.sp > 0 && !seq) next = stack[(--w.sp) * kBlock]; // (a sequential walk waits for the leaf test)
                 }
                 w.ref = next;
             }
@@ -751,12 +757,12 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float &t_init, float t
             if (has) {
                 region_tick<COUNT>(n, kRegLeaf);
                 bool near = false;
-                test_leaf<COUNT, WIDE>(P, w.pleaf, o, d, t_stop, w.h, near, n);
+                test_leaf<COUNT, true>(P, w.pleaf, o, d, t_stop, w.h, near, n);
                 w.pleaf = 0;
-                // see kCullSlack: start over on the binary tree. This slice's wide code must not step the lane
+                // see kCullSlack: start over as a sequential walk. This slice's code must not step the lane
                 // again, so the slice ends here for the whole wave (steps is wave-uniform; the event is rare).
-                const bool redo = WIDE && near && !exact && t_init > 0.0f;
-                if (WIDE && __builtin_amdgcn_ballot_w64(redo) != 0) steps = slice;
+                const bool redo = near && !seq && t_init > 0.0f;
+                if (__builtin_amdgcn_ballot_w64(redo) != 0) steps = slice;
                 if (redo) {
                     walk_reset(P.root, t_init, w);
                     t_init = -t_init;
@@ -767,7 +773,13 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float &t_init, float t
                 } else if (w.ref > kDone) { // standing on the next leaf: park it, step off
                     w.pleaf = w.ref;
                     w.ref = kDone;
-                    if (w.sp > 0) w.ref = stack[(--w.sp) * kBlock];
+                    if (w.sp > 0 && !seq) w.ref = stack[(--w.sp) * kBlock];
+                } else if (w.ref == kDone && w.sp > 0) { // a sequential walk waited for this leaf: on it goes
+                    w.ref = stack[(--w.sp) * kBlock];
+                    if (w.ref > kDone) { // to another leaf: that one is next, and again the walk waits for it
+                        w.pleaf = w.ref;
+                        w.ref = kDone;
+                    }
                 }
             }
         }

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
     Tally n = {};
     int slot = -1;
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
-    float t_stop = -1.0f;
+    float t_stop = -1.0f, t_init = kNoHit; // t_init goes negative while the walk is a sequential one (kernel.h, kCullSlack)
     Walk wk = {};
     wk.ref = kDone;
     bool exhausted = false; // wave-uniform
@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
                 ro = xyz(r0);
                 rd = xyz(r1);
                 t_stop = r1.w;
-                walk_begin<false>(P, rd, r0.w, wk);
+                t_init = r0.w;
+                walk_begin<false>(P, rd, t_init, wk);
             }
             res_next = res_next + (uint32_t)n_empty < res_end ? res_next + (uint32_t)n_empty : res_end;
         }
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
             if (exhausted) break;
             continue;
         }
-        { float t0 = kNoHit; walk_slice<false, STACK, false>(P, ro, rd, t0, t_stop, stack, wk, n); }
+        walk_slice<false, STACK, false>(P, ro, rd, t_init, t_stop, stack, wk, n);
         if (slot >= 0 && wk.ref == kDone && wk.pleaf == 0) {
             if (t_stop != -1.0f) {
                 // shadow ray: visibility, then the bounce ray of the same vertex (same origin)
@@ -190,7 +191,8 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
                 rd = xyz(nx);
                 t_stop = -1.0f;
                 q_at(Q, qRay1, (uint32_t)slot) = pack(rd, -1.0f); // shade_kernel reads the direction it hit along
-                { float t0 = kNoHit; walk_begin<false>(P, rd, t0, wk); }
+                t_init = kNoHit;
+                walk_begin<false>(P, rd, t_init, wk);
             } else {
                 float t = wk.h.face < 0 ? kNoHit : wk.h.t;
                 Q.hit[(uint32_t)slot] = make_float4(t, wk.h.u, wk.h.v, __int_as_float(wk.h.face));

@@ -2,7 +2,8 @@
 oracle and on the GPU with each form of the tree, compared bit for bit. The suite compares at sizes the
 oracle finishes in seconds; this is the same comparison at the size the bench runs.
 
-  python3 tests/full_size_gpu.py [--scene many_lights|dragon|glass] [--res 1024] [--spp 50] [--batches 4] [--threads 16]
+  python3 tests/full_size_gpu.py [--scene many_lights|dragon|glass|grid] [--res 1024] [--spp 50] [--batches 4] [--threads 16]
+  (grid = the synthetic 10 M-triangle scene of BASELINE config 5: --scene grid --res 4096 --spp 16 --batches 1)
 """
 import argparse
 import os
@@ -25,9 +26,10 @@ def main():
     ap.add_argument("--spp", type=int, default=50)
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--side", type=int, default=2236, help="grid scene: quads per side")
     a = ap.parse_args()
     gen = {"many_lights": scenes.write_many_lights_standin, "dragon": scenes.write_dragon_standin,
-           "glass": scenes.write_glass_mirror_standin}[a.scene]
+           "glass": scenes.write_glass_mirror_standin, "grid": lambda d: scenes.write_synthetic_grid(d, side=a.side)}[a.scene]
     clear = (1.0, 1.0, 1.0) if a.scene == "glass" else (0.0, 0.0, 0.0)
     with tempfile.TemporaryDirectory() as d:
         kw = {"clear_texture": scenes.write_sky_hdr(d + "/sky.hdr")} if a.scene == "glass" else {}

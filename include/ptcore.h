@@ -52,8 +52,8 @@ typedef struct {
      * with another one parked, [1] walk finished except for a parked leaf, [2] walk finished,
      * waiting for its result handler. (Lanes whose pixel is complete are 64*iters - lanes - these.) */
     uint64_t node_step_idle[3];
-    /* Walks of the four-wide tree that met two candidates within 2^-18 of each other and were repeated
-     * on the binary tree, whose order of leaves is the reference's (kernel.h, kCullSlack). */
+    /* Speculative walks that met two candidates within 2^-12 of each other and were repeated as a
+     * sequential walk of the binary tree, the reference's loop step for step (kernel.h, kCullSlack). */
     uint64_t redone_walks;
 } pt_counters;
 
@@ -145,10 +145,10 @@ float pt_kernel_ms(pt_context *ctx, int launches_back);
 /* Which form of the uploaded tree the render launches walk: 2 = the reference's binary tree, 4 = the
  * same tree folded four-wide at upload, 0 = not chosen yet. Both give the same hits; the first render
  * launch after pt_bvh_upload times a 2-sample launch on each and keeps the faster (PT_TREE=binary|wide
- * in the environment forces one). Only the binary tree meets leaves in the reference's order; a walk of
- * the four-wide one that finds two candidates within rounding of each other starts over on the binary
- * tree (pt_counters.redone_walks), so the choice never shows in a pixel. Faces on the same three points
- * would make every ray through them do that: pt_bvh_upload looks for such faces and then answers 2 at once. */
+ * in the environment forces one). A walk of either that finds two candidates within rounding of each
+ * other starts over as a sequential walk of the binary tree in the reference's order
+ * (pt_counters.redone_walks), so the choice never shows in a pixel. Faces on the same three points would
+ * make every ray through them do that: pt_bvh_upload looks for such faces and then answers 2 at once. */
 int pt_walk_tree(pt_context *ctx);
 
 /* Bytes of device memory held by the context (scene + BVH + LST + image). */

@@ -24,9 +24,9 @@
 //  * One handler per path vertex (vertex_handler): the direct term and the next
 //    bounce ray are finished before the shadow walk, which only answers "visible?".
 //  * The walk (walk_slice) is sliced and speculative, on the reference's tree folded
-//    four-wide at upload (layout.h) for rays with finite direction reciprocals; a wide walk
-//    that meets two candidates within rounding of each other starts over on the binary
-//    tree, whose order of leaves is the reference's (kCullSlack).
+//    four-wide at upload (layout.h) for rays with finite direction reciprocals; a walk
+//    that meets two candidates within rounding of each other starts over as a sequential
+//    walk of the binary tree, the reference's loop step for step (kCullSlack).
 //  * Independent pairs of float operations are written on 2-vectors (packed fp32).
 //  * Tiles are dispatched heaviest first from the costs the previous launch recorded;
 //    large images give a wave two pixels per lane (render_body).
@@ -321,7 +321,7 @@ struct Tally {
     // wave-level occupancy of each code region (instrumented variant only): iterations executed by
     // the wave, and the sum of lanes that were active in them
     uint32_t w_iters[6], w_lanes[6];
-    uint32_t redone; // wide walks repeated on the binary tree (see kCullSlack)
+    uint32_t redone; // speculative walks repeated as sequential ones (see kCullSlack)
     uint32_t w_idle[3]; // lanes that sat out a node step: blocked on two leaves | walk over but for a parked leaf | waiting for a handler
     unsigned long long *w_time; // LDS: shader-clock ticks per region, written by the wave's leader lane
 };

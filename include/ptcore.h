@@ -52,8 +52,8 @@ typedef struct {
      * with another one parked, [1] walk finished except for a parked leaf, [2] walk finished,
      * waiting for its result handler. (Lanes whose pixel is complete are 64*iters - lanes - these.) */
     uint64_t node_step_idle[3];
-    /* Speculative walks that met two candidates within 2^-12 of each other and were repeated as a
-     * sequential walk of the binary tree, the reference's loop step for step (kernel.h, kCullSlack). */
+    /* Speculative walks whose winner had another candidate within 2^-12 of it and that were repeated as
+     * a sequential walk of the binary tree, the reference's loop step for step (kernel.h, kCullSlack). */
     uint64_t redone_walks;
 } pt_counters;
 

@@ -280,6 +280,7 @@ constexpr float kNoHit = 1e30f;
 
 struct HitLite {
     float t, u, v;
+    float t2; // distance of the nearest other candidate tested (see kCullSlack)
     int32_t face; // -1: miss
     uint32_t material;
     bool early;   // walk stopped at an occluder closer than t_stop (shadow rays only)
@@ -303,18 +304,14 @@ constexpr float kBand = 1e-4f;
 // best distance and not against another. So a speculative walk
 //  (a) on the wide tree, culls boxes against the best distance times kCullSlack (on the binary tree its stale
 //      distance already culls less than the reference does): every candidate that close to the best is tested;
-//  (b) notices when it tests a candidate within kNearUlps of the best so far;
-//  (c) then starts over as a SEQUENTIAL walk of the binary tree: a leaf is tested before the walk goes on, which
-//      is the reference's loop (bvh.cu:239-286) step for step. The ray's t_init, negated, marks such a walk
-//      until the next ray (walk_slice); no lane state is added.
+//  (b) keeps, beside the best distance, the distance of the nearest OTHER candidate it tested (HitLite::t2);
+//  (c) if at its end that one lies within kNearHi of the winner, starts over as a SEQUENTIAL walk of the binary
+//      tree (render_body): a leaf is tested before the walk goes on, which is the reference's loop
+//      (bvh.cu:239-286) step for step. The ray's t_init, negated, marks such a walk until the next ray.
 // Box and triangle arithmetic agree to a few units of 2^-24, far inside both margins, so a speculative walk that
 // noticed nothing has a winner every other candidate loses to in any order and under any culling.
 constexpr float kCullSlack = 1.0f + 0x1p-13f;
-constexpr uint32_t kNearUlps = 4096u; // 2^-12 .. 2^-11 of the distance, twice the cull slack and more
-// t >= 0 and best > 0 are ordered like their bit patterns, so "within kNearUlps" is one subtraction and one
-// unsigned compare (the 1e30 of "no hit yet" is far from any distance)
-// (`best` must be a hit's distance, not the t_init a shadow walk starts from: callers test h.face >= 0)
-PT_DEV bool near_to(float t, float best) { return __float_as_uint(t) - __float_as_uint(best) + kNearUlps <= 2u * kNearUlps; }
+constexpr float kNearHi = 1.0f + 0x1p-12f; // twice the cull slack
 
 struct Tally {
     uint32_t samples, rays, inner, tris, walks, shaded, bounces;
@@ -395,6 +392,7 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
                      Tally &n) {
     HitLite h;
     h.t = t_init;
+    h.t2 = kNoHit;
     h.u = h.v = 0.f;
     h.face = -1;
     h.material = 0;
@@ -509,10 +507,17 @@ struct Walk {
     HitLite h;
 };
 
+// HitLite::t2: a candidate at distance t (already known to hit the triangle in front of the origin) is about
+// to be compared with the best so far. Whichever of the two does not end up as the best is a candidate
+// for "nearest other". The distance a shadow walk starts from is not a hit and does not count.
+PT_DEV void note_other(HitLite &h, float t) {
+    const float best = h.face >= 0 ? h.t : kNoHit;
+    h.t2 = __builtin_fminf(h.t2, __builtin_fmaxf(t, best));
+}
+
 // Moeller-Trumbore on one pre-gathered triangle (src/intersect.cu:12-81, non-culling branch)
 // followed by the "closer" test of intersect_face (src/intersect.cu:100).
-template <bool NEAR>
-PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop, HitLite &h, bool &near) {
+PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop, HitLite &h) {
     f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
     f3 pvec = cross(d, e2);
     float det = dot(e1, pvec);
@@ -525,7 +530,7 @@ PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop
     float v = dot(d, qvec) * inv_det;
     if (v <= -PT_EPS_UP || (u + v) > 1.0f) return;
     float t = dot(e2, qvec) * inv_det;
-    if (NEAR && t >= 0 && h.face >= 0 && near_to(t, h.t)) near = true;
+    if (t >= 0) note_other(h, t);
     if (t >= 0 && t < h.t) {
         h.t = t;
         h.u = u;
@@ -540,9 +545,8 @@ PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop
 // operation (same operations, same order and rounding as test_triangle; the reference's early
 // returns become the `ok` flags, and triangle 0 is committed before triangle 1 is compared, as in
 // the reference's loop over a leaf, bvh.cu:252-256).
-template <bool NEAR>
 PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float4 b1, float4 c1, bool second, f3 o, f3 d,
-                               float t_stop, HitLite &h, bool &near) {
+                               float t_stop, HitLite &h) {
     const v2f dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
     const v2f v0x = {a0.x, a1.x}, v0y = {a0.y, a1.y}, v0z = {a0.z, a1.z};
     const v2f e1x = {a0.w, a1.w}, e1y = {b0.x, b1.x}, e1z = {b0.y, b1.y};
@@ -560,7 +564,7 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
     v2f uv = u + v;
     const bool in0 = !(det.x > -PT_EPS_UP && det.x < PT_EPS_UP) && !(u.x <= -PT_EPS_UP || u.x > 1.0f) &&
                      !(v.x <= -PT_EPS_UP || uv.x > 1.0f) && t.x >= 0;
-    if (NEAR && in0 && h.face >= 0 && near_to(t.x, h.t)) near = true;
+    if (in0) note_other(h, t.x);
     bool ok0 = in0 && t.x < h.t;
     if (ok0) {
         h.t = t.x;
@@ -572,7 +576,7 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
     }
     const bool in1 = second && !(det.y > -PT_EPS_UP && det.y < PT_EPS_UP) && !(u.y <= -PT_EPS_UP || u.y > 1.0f) &&
                      !(v.y <= -PT_EPS_UP || uv.y > 1.0f) && t.y >= 0;
-    if (NEAR && in1 && h.face >= 0 && near_to(t.y, h.t)) near = true;
+    if (in1) note_other(h, t.y);
     bool ok1 = in1 && t.y < h.t;
     if (ok1) {
         h.t = t.y;
@@ -586,8 +590,8 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
 
 // Leaves of the reference builder hold one or two faces (src/bvh.cu:143): both records are
 // fetched before either is tested so the second fetch does not wait for the first test.
-template <bool COUNT, bool NEAR>
-PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_stop, HitLite &h, bool &near, Tally &n) {
+template <bool COUNT>
+PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_stop, HitLite &h, Tally &n) {
     uint32_t first = leaf & 0x0FFFFFFFu;
     uint32_t count = ((leaf >> 28) & 7u) + 1;
     const float4 *tp = (const float4 *)(P.tris + first);
@@ -595,10 +599,10 @@ PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_
     float4 a0 = tp[0], b0 = tp[1], c0 = tp[2];
     float4 a1 = tp[second + 0], b1 = tp[second + 1], c1 = tp[second + 2];
     if (COUNT) n.tris += count;
-    test_triangle_pair<NEAR>(a0, b0, c0, a1, b1, c1, count > 1, o, d, t_stop, h, near);
+    test_triangle_pair(a0, b0, c0, a1, b1, c1, count > 1, o, d, t_stop, h);
     for (uint32_t k = 2; k < count; k++) {
         const float4 *tq = (const float4 *)(P.tris + first + k);
-        test_triangle<NEAR>(tq[0], tq[1], tq[2], o, d, t_stop, h, near);
+        test_triangle(tq[0], tq[1], tq[2], o, d, t_stop, h);
     }
 }
 
@@ -616,6 +620,7 @@ PT_DEV void walk_reset(uint32_t root, float t_init, Walk &w) {
     w.pleaf = 0;
     w.sp = 0;
     w.h.t = t_init;
+    w.h.t2 = kNoHit;
     w.h.u = w.h.v = 0.f;
     w.h.face = -1;
     w.h.material = 0;
@@ -633,7 +638,7 @@ PT_DEV void walk_begin(const KernelParams &P, f3 d, float &t_init, Walk &w) {
 }
 
 template <bool COUNT, int STACK, bool WIDE>
-PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float &t_init, float t_stop, uint32_t *stack, Walk &w, Tally &n) {
+PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_stop, uint32_t *stack, Walk &w, Tally &n) {
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float inf = __builtin_inff();
     const bool inf_rinv = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
@@ -756,18 +761,9 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float &t_init, float t
             if (__builtin_amdgcn_ballot_w64(has) == 0) break;
             if (has) {
                 region_tick<COUNT>(n, kRegLeaf);
-                bool near = false;
-                test_leaf<COUNT, true>(P, w.pleaf, o, d, t_stop, w.h, near, n);
+                test_leaf<COUNT>(P, w.pleaf, o, d, t_stop, w.h, n);
                 w.pleaf = 0;
-                // see kCullSlack: start over as a sequential walk. This slice's code must not step the lane
-                // again, so the slice ends here for the whole wave (steps is wave-uniform; the event is rare).
-                const bool redo = near && !seq && t_init > 0.0f;
-                if (__builtin_amdgcn_ballot_w64(redo) != 0) steps = slice;
-                if (redo) {
-                    walk_reset(P.root, t_init, w);
-                    t_init = -t_init;
-                    if (COUNT) n.redone++;
-                } else if (w.h.early) {
+                if (w.h.early) {
                     w.ref = kDone;
                     w.sp = 0;
                 } else if (w.ref > kDone) { // standing on the next leaf: park it, step off
@@ -1498,7 +1494,15 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         }
         walk_slice<COUNT, STACK, WIDE>(P, s.ro, s.rd, s.t_init, s.t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
-        const bool finished = active && wk.ref == kDone && wk.pleaf == 0;
+        bool finished = active && wk.ref == kDone && wk.pleaf == 0;
+        // A speculative walk whose winner has another candidate within rounding of it starts over as a sequential
+        // one (see kCullSlack). Not after an early exit: whatever is nearest there, the light is hidden.
+        if (finished && s.t_init > 0.0f && !wk.h.early && wk.h.face >= 0 && wk.h.t2 <= wk.h.t * kNearHi) {
+            s.t_init = -s.t_init;
+            walk_reset(P.root, -s.t_init, wk);
+            finished = false;
+            if (COUNT) n.redone++;
+        }
 
         if (finished && s.mode == kModeNee) { // shadow results are handled on the spot
             unsigned long long tn0 = stamp<COUNT>();

@@ -167,6 +167,11 @@ __global__ void __launch_bounds__(64, PT_WALK_WAVES) queue_walk_kernel(KernelPar
             continue;
         }
         walk_slice<false, STACK, false>(P, ro, rd, t_init, t_stop, stack, wk, n);
+        if (slot >= 0 && wk.ref == kDone && wk.pleaf == 0 && t_init > 0.0f && !wk.h.early && wk.h.face >= 0 &&
+            wk.h.t2 <= wk.h.t * kNearHi) { // see kCullSlack in kernel.h: once more, sequentially
+            t_init = -t_init;
+            walk_reset(P.root, -t_init, wk);
+        }
         if (slot >= 0 && wk.ref == kDone && wk.pleaf == 0) {
             if (t_stop != -1.0f) {
                 // shadow ray: visibility, then the bounce ray of the same vertex (same origin)

@@ -282,7 +282,6 @@ struct HitLite {
     float t, u, v;
     float t2; // distance of the nearest other candidate tested (see kCullSlack)
     int32_t face; // -1: miss
-    uint32_t material;
     bool early;   // walk stopped at an occluder closer than t_stop (shadow rays only)
 };
 
@@ -395,7 +394,6 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
     h.t2 = kNoHit;
     h.u = h.v = 0.f;
     h.face = -1;
-    h.material = 0;
     h.early = false;
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float inf = __builtin_inff();
@@ -458,7 +456,6 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
                     h.u = u;
                     h.v = v;
                     h.face = (int32_t)__float_as_uint(c.y);
-                    h.material = __float_as_uint(c.z);
                     if (t <= t_stop) h.early = true;
                 }
             }
@@ -536,7 +533,6 @@ PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop
         h.u = u;
         h.v = v;
         h.face = (int32_t)__float_as_uint(c.y);
-        h.material = __float_as_uint(c.z);
         if (t <= t_stop) h.early = true;
     }
 }
@@ -571,7 +567,6 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
         h.u = u.x;
         h.v = v.x;
         h.face = (int32_t)__float_as_uint(c0.y);
-        h.material = __float_as_uint(c0.z);
         if (t.x <= t_stop) h.early = true;
     }
     const bool in1 = second && !(det.y > -PT_EPS_UP && det.y < PT_EPS_UP) && !(u.y <= -PT_EPS_UP || u.y > 1.0f) &&
@@ -583,7 +578,6 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
         h.u = u.y;
         h.v = v.y;
         h.face = (int32_t)__float_as_uint(c1.y);
-        h.material = __float_as_uint(c1.z);
         if (t.y <= t_stop) h.early = true;
     }
 }
@@ -623,7 +617,6 @@ PT_DEV void walk_reset(uint32_t root, float t_init, Walk &w) {
     w.h.t2 = kNoHit;
     w.h.u = w.h.v = 0.f;
     w.h.face = -1;
-    w.h.material = 0;
     w.h.early = false;
     if (w.ref > kDone) { // the whole tree is one leaf
         w.pleaf = w.ref;
@@ -1051,7 +1044,7 @@ PT_DEV void shadow_result(const HitLite &h, Path &s, Tally &n) {
 
 // Main-ray result: one handler per path vertex. Returns true when the path ended (the caller adds
 // s.light to the pixel and starts the next sample); otherwise s holds the next ray.
-template <bool COUNT, bool MATERIAL_FROM_SHADE = false>
+template <bool COUNT>
 PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n) {
     // ---- main-ray result: one handler per path vertex ----
     region_tick<COUNT>(n, kRegMain);
@@ -1060,9 +1053,12 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
     const bool sh = hit.face >= 0;
     GShade gs;
     GMaterial m;
-    if (sh) { // both records are addressed by the walk's result, so the two fetches overlap
+    if (sh) {
+        // The material index comes with the shading record. (Carrying the copy in GTri through the walk, so
+        // that both fetches start together, costs a register for the whole walk: with the walk's second
+        // distance t2 that meant spills, 33.0 against 32.0 ms.)
         gs = P.shade[hit.face];
-        m = P.materials[MATERIAL_FROM_SHADE ? gs.material : hit.material];
+        m = P.materials[gs.material];
     }
     if (s.pending) {
         // evaluate_direct_p: only the LST node whose face this ray hit contributes

@@ -224,7 +224,6 @@ __global__ void __launch_bounds__(64, 4) queue_shade_kernel(KernelParams P, Queu
         hit.u = hv.y;
         hit.v = hv.z;
         hit.face = __float_as_int(hv.w);
-        hit.material = 0;
         hit.early = false;
         float4 r1 = q_at(Q, qRay1, slot), li = q_at(Q, qLight, slot), th = q_at(Q, qThr, slot), fc = q_at(Q, qFcos, slot);
         float4 g0 = q_at(Q, qRng0, slot), g1 = q_at(Q, qRng1, slot);
@@ -249,7 +248,7 @@ __global__ void __launch_bounds__(64, 4) queue_shade_kernel(KernelParams P, Queu
         s.nee_face = -1;
         f3 total = xyz(q_at(Q, qTotal, slot));
 
-        bool end_path = vertex_handler<false, true>(P, hit, s, n);
+        bool end_path = vertex_handler<false>(P, hit, s, n);
         if (s.mode == kModeNee) s.pending = true; // shadow_result would set it before the bounce ray's hit
         if (end_path) {
             total = total + s.light;

@@ -1384,7 +1384,7 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
     f3 total = mk3(0, 0, 0);
     int sample = 0, turn = 0;
     int q = -1; // the pool pixel this lane is rendering, -1 = none
-    int px = 0, py = 0;
+    // (the pixel's coordinates follow from q and the tile: recomputed where needed, not kept in registers)
     bool need_camera = false;
     bool need_switch = true; // lane is at a turn boundary (or idle)
 
@@ -1401,8 +1401,6 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
             if (inside) {
                 s.rng = g;
                 q = (int)qq;
-                px = x;
-                py = y;
                 need_camera = true;
                 need_switch = false;
             }
@@ -1433,6 +1431,8 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
                 f3 mean = total * P.exposure_scale;
                 mean = mean / (float)P.current_samples;
                 int total_samples = P.previous_samples + P.current_samples;
+                int px, py;
+                pool_pixel<ROWS>(tx, ty, (uint32_t)q, &px, &py);
                 float *p = img + 3 * ((size_t)py * (size_t)P.width + (size_t)px);
                 f3 last = mk3(p[0], p[1], p[2]);
                 f3 next = last * ((float)P.previous_samples / (float)total_samples) +
@@ -1463,7 +1463,6 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
                 s.rng = new_rng;
                 total = new_total;
                 sample = new_sample;
-                pool_pixel<ROWS>(tx, ty, new_q, &px, &py);
             } else if (need_switch && !more) {
                 q = -1; // completed or idle, and nothing waits
             }
@@ -1476,6 +1475,8 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         if (__builtin_amdgcn_ballot_w64(q >= 0) == 0) break; // no pixel in flight and none waiting
 
         if (need_camera) {
+            int px, py;
+            pool_pixel<ROWS>(tx, ty, (uint32_t)q, &px, &py);
             start_sample<COUNT>(P, px, py, s, n);
             need_camera = false;
         }

@@ -120,10 +120,10 @@ struct KernelParams {
 
 // ---- XORWOW ------------------------------------------------------------------------
 
+// (curand's state also caches the second value of a Box-Muller pair. The kernel draws normals only as the
+// two jitter offsets of a sample, renderer.cu:376-380, i.e. always a whole pair: rng_normal_pair, no cache.)
 struct Rng {
     uint32_t v0, v1, v2, v3, v4, d;
-    float extra;
-    uint32_t have_extra;
 };
 
 PT_DEV uint32_t rng_next(Rng &s) {
@@ -192,8 +192,6 @@ PT_DEV void rng_init(Rng &s, const uint32_t *__restrict__ jump, uint32_t seed_lo
     rng_seed(v, &s.d, seed_lo, seed_hi);
     rng_jump(v, jump, subsequence);
     s.v0 = v[0]; s.v1 = v[1]; s.v2 = v[2]; s.v3 = v[3]; s.v4 = v[4];
-    s.extra = 0.f;
-    s.have_extra = 0;
 }
 
 // The same state reached in two jumps: `base` is the state of the tile's first pixel (tile_rng_kernel
@@ -204,17 +202,12 @@ PT_DEV void rng_init_from(Rng &s, const uint32_t *__restrict__ jump, const uint3
     s.d = base[5];
     rng_jump(v, jump, delta);
     s.v0 = v[0]; s.v1 = v[1]; s.v2 = v[2]; s.v3 = v[3]; s.v4 = v[4];
-    s.extra = 0.f;
-    s.have_extra = 0;
 }
 
 PT_DEV float rng_uniform(Rng &s) { return (float)rng_next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
 
-PT_DEV float rng_normal(Rng &s) {
-    if (s.have_extra) {
-        s.have_extra = 0;
-        return s.extra;
-    }
+// Two calls of curand_normal: the first computes the pair and returns r * sin, the second returns the cached r * cos.
+PT_DEV void rng_normal_pair(Rng &s, float *first, float *second) {
     uint32_t x = rng_next(s), y = rng_next(s);
     const float two_pi_scale = 2.3283064e-10f * 6.2831855f;
     float u = (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
@@ -222,9 +215,8 @@ PT_DEV float rng_normal(Rng &s) {
     float r = __builtin_sqrtf(-2.0f * pt_logf(u));
     float sn, cs;
     pt_sincosf(v, &sn, &cs);
-    s.extra = r * cs;
-    s.have_extra = 1;
-    return r * sn;
+    *first = r * sn;
+    *second = r * cs;
 }
 
 // ---- textures ------------------------------------------------------------------------
@@ -1006,8 +998,10 @@ struct Path {
 // First ray of a sample (render_kernel's loop body up to integrate_Li, renderer.cu:376-388).
 template <bool COUNT>
 PT_DEV void start_sample(const KernelParams &P, int px, int py, Path &s, Tally &n) {
-    float sx = (float)px + 0.33f * rng_normal(s.rng);
-    float sy = (float)py + 0.33f * rng_normal(s.rng);
+    float nx, ny;
+    rng_normal_pair(s.rng, &nx, &ny);
+    float sx = (float)px + 0.33f * nx;
+    float sy = (float)py + 0.33f * ny;
     float u = (2 * sx - (float)P.width) / (float)P.height;
     float v = (2 * sy - (float)P.height) / (float)P.height;
     camera_ray(P, u, v, &s.ro, &s.rd);
@@ -1331,8 +1325,6 @@ PT_DEV void ring_get(const uint32_t *ring, uint32_t pos, uint32_t &q, Rng &g, f3
     q = ring[0 * kRing + pos];
     g.v0 = ring[1 * kRing + pos]; g.v1 = ring[2 * kRing + pos]; g.v2 = ring[3 * kRing + pos];
     g.v3 = ring[4 * kRing + pos]; g.v4 = ring[5 * kRing + pos]; g.d = ring[6 * kRing + pos];
-    g.extra = 0.f;    // a sample draws its two jitter normals as one Box-Muller pair (renderer.cu:376-380),
-    g.have_extra = 0; // so nothing is cached at a sample boundary
     total = mk3(__uint_as_float(ring[7 * kRing + pos]), __uint_as_float(ring[8 * kRing + pos]), __uint_as_float(ring[9 * kRing + pos]));
     sample = (int)ring[10 * kRing + pos];
 }
@@ -1583,7 +1575,8 @@ __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, in
     Rng rng;
     rng_init(rng, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(py * P.width + px) : 0u);
     if (!inside) return;
-    float nx = rng_normal(rng), ny = rng_normal(rng);
+    float nx, ny;
+    rng_normal_pair(rng, &nx, &ny);
     if (!P.jitter) nx = ny = 0;
     float sx = (float)px + 0.33f * nx, sy = (float)py + 0.33f * ny;
     float u = (2 * sx - (float)P.width) / (float)P.height;

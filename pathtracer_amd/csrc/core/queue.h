@@ -71,7 +71,7 @@ PT_DEV void save_path(const QueueParams &Q, uint32_t slot, const Path &s, f3 tot
     q_at(Q, qFcos, slot) = pack(s.f_cos_next, 0.f);
     q_at(Q, qTotal, slot) = pack(total, 0.f);
     q_at(Q, qRng0, slot) = make_float4(__uint_as_float(s.rng.v0), __uint_as_float(s.rng.v1), __uint_as_float(s.rng.v2), __uint_as_float(s.rng.v3));
-    q_at(Q, qRng1, slot) = make_float4(__uint_as_float(s.rng.v4), __uint_as_float(s.rng.d), s.rng.extra, __uint_as_float(s.rng.have_extra));
+    q_at(Q, qRng1, slot) = make_float4(__uint_as_float(s.rng.v4), __uint_as_float(s.rng.d), 0.f, 0.f);
 }
 
 // Wave-aggregated append of the lanes with `keep` to list[which]; all lanes of the wave call it.
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64, 4) queue_shade_kernel(KernelParams P, Queu
         float4 r1 = q_at(Q, qRay1, slot), li = q_at(Q, qLight, slot), th = q_at(Q, qThr, slot), fc = q_at(Q, qFcos, slot);
         float4 g0 = q_at(Q, qRng0, slot), g1 = q_at(Q, qRng1, slot);
         s.rng.v0 = __float_as_uint(g0.x); s.rng.v1 = __float_as_uint(g0.y); s.rng.v2 = __float_as_uint(g0.z); s.rng.v3 = __float_as_uint(g0.w);
-        s.rng.v4 = __float_as_uint(g1.x); s.rng.d = __float_as_uint(g1.y); s.rng.extra = g1.z; s.rng.have_extra = __float_as_uint(g1.w);
+        s.rng.v4 = __float_as_uint(g1.x); s.rng.d = __float_as_uint(g1.y);
         s.ro = mk3(0, 0, 0);
         s.rd = xyz(r1);
         s.t_init = kNoHit;

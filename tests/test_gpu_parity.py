@@ -331,6 +331,31 @@ def test_coincident_faces_keep_the_reference_tie_rule(cornell_like, monkeypatch)
         r.close()
 
 
+def test_height_field_of_tiny_triangles(scene_dir, monkeypatch):
+    """A height field of triangles a thousandth of the viewing distance long (the shape of BASELINE config 5):
+    Moeller-Trumbore accepts a ray that passes close to an edge in BOTH neighbours, so which of two hits at
+    (nearly) the same distance wins depends on the order of the tests and on what the boxes culled. The
+    kernel's speculative walks notice such pairs and repeat the ray in the reference's order; without that,
+    604 pixels of the full-size configuration differed. Both trees, two launches."""
+    b = util.load_bundle(scenes.write_synthetic_grid(scene_dir, name="grid_small", side=500, emitters=4))
+    assert len(b.scene.faces) == 2 * 500 * 500 + 8
+    cpu = None
+    for tree in ("binary", "wide"):
+        monkeypatch.setenv("PT_TREE", tree)
+        r = core.Renderer(0)
+        try:
+            o = _setup(r, b, 448, 320)
+            gpu = r.render(42, 12, 6)
+            if cpu is None:
+                cpu = o.render(42, 12, 6)
+            _assert_images_match(gpu, cpu)
+            c = r.count_batch(42, 6)
+            assert c["redone_walks"] > 50, c["redone_walks"]  # the case is there (with the start-over switched
+            # off, 2 floats of this image differ on the binary tree and 8 on the wide one)
+        finally:
+            r.close()
+
+
 def test_two_pixels_per_lane_tiles(cornell_like, monkeypatch):
     """Large images use 8x16 tiles whose 128 pixels are swapped between the 64 lanes every few
     samples (PT_TILE_ROWS=16 forces that kernel at a small size): ragged right and top edges, more

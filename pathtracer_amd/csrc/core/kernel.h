@@ -465,7 +465,9 @@ PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_st
 //    triangles are tested later, in the order the leaves were found. The lane therefore
 //    culls with a slightly stale (larger) best distance and may visit nodes the reference
 //    would have skipped; every face the reference tests is still tested, in the same relative
-//    order, with the same strict "closer" rule, so the result is the same.
+//    order, with the same strict "closer" rule. The result is the same unless one of the extra
+//    faces lies within rounding of the winner: those walks are found out and repeated
+//    sequentially (kCullSlack above; a sequential walk never goes on with a leaf untested).
 //  * Wave-uniform phases: the node loop runs while no lane is blocked (holding a parked leaf
 //    AND standing on another one), so no lane idles while others descend; then one leaf phase
 //    serves every parked leaf.

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernel.h"
@@ -124,36 +125,58 @@ H3 h_rgb_to_radiometric(H3 color, float intensity) {
 
 // Two faces on the same three points are hit at the same distance (bit for bit when the corners are in
 // the same order, within an ulp otherwise), and the reference keeps the one its traversal meets first.
-// Only the binary tree meets leaves in that order (kernel.h, walk_slice), so a scene with such faces is
-// walked on the binary tree. One 64-bit hash per face over its sorted corners, sorted; equal hashes are
-// compared for real.
+// The kernel repeats such a ray sequentially in the reference's order (kernel.h, kCullSlack); a scene with
+// such faces would do that for every ray through them, so it is walked on the binary tree, the cheaper
+// one to repeat from, without timing the other. One 64-bit hash per face over its sorted corners, sorted (on up to 16 threads, each
+// taking a share of the hash range); equal hashes are compared for real.
 bool has_coincident_faces(const std::vector<GShade> &shade) {
-    struct Key {
-        uint64_t hash;
-        uint32_t face;
-    };
     auto corners = [](const GShade &g, float out[9]) {
         int order[3] = {0, 1, 2};
         std::sort(order, order + 3, [&](int a, int b) { return memcmp(g.pos[a], g.pos[b], 12) < 0; });
         for (int k = 0; k < 3; k++) memcpy(out + 3 * k, g.pos[order[k]], 12);
     };
-    std::vector<Key> keys(shade.size());
-    for (size_t f = 0; f < shade.size(); f++) {
-        float c[9];
-        corners(shade[f], c);
-        uint64_t h = 1469598103934665603ull; // FNV-1a over the 36 bytes
-        const unsigned char *b = (const unsigned char *)c;
-        for (int i = 0; i < 36; i++) h = (h ^ b[i]) * 1099511628211ull;
-        keys[f] = {h, (uint32_t)f};
-    }
-    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.hash < b.hash; });
-    for (size_t i = 1; i < keys.size(); i++) {
-        if (keys[i].hash != keys[i - 1].hash) continue;
-        float a[9], b[9];
-        corners(shade[keys[i].face], a);
-        corners(shade[keys[i - 1].face], b);
-        if (memcmp(a, b, sizeof(a)) == 0) return true;
-    }
+    const size_t n = shade.size();
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned threads = n < 100000 ? 1u : (hw == 0 ? 4u : (hw > 16u ? 16u : hw));
+    std::vector<uint64_t> hash(n);
+    auto run = [&](auto &&body) { // body(t) on `threads` threads
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; t++) pool.emplace_back(body, t);
+        body(0u);
+        for (auto &th : pool) th.join();
+    };
+    run([&](unsigned t) {
+        for (size_t f = n * t / threads; f < n * (t + 1) / threads; f++) {
+            float c[9];
+            corners(shade[f], c);
+            uint64_t h = 1469598103934665603ull; // FNV-1a over the 36 bytes
+            const unsigned char *b = (const unsigned char *)c;
+            for (int i = 0; i < 36; i++) h = (h ^ b[i]) * 1099511628211ull;
+            hash[f] = h;
+        }
+    });
+    // thread t takes the faces whose hash falls into its share of the hash range: equal hashes meet in one thread
+    std::vector<char> found(threads, 0);
+    run([&](unsigned t) {
+        struct Key {
+            uint64_t hash;
+            uint32_t face;
+        };
+        std::vector<Key> keys;
+        keys.reserve(n / threads + n / (8 * threads) + 16);
+        for (size_t f = 0; f < n; f++)
+            if ((unsigned)(((hash[f] >> 32) * threads) >> 32) == t) keys.push_back({hash[f], (uint32_t)f});
+        std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) { return a.hash < b.hash; });
+        for (size_t i = 1; i < keys.size() && !found[t]; i++) {
+            if (keys[i].hash != keys[i - 1].hash) continue;
+            float a[9], b[9];
+            corners(shade[keys[i].face], a);
+            corners(shade[keys[i - 1].face], b);
+            if (memcmp(a, b, sizeof(a)) == 0) found[t] = 1;
+        }
+    });
+    for (char f : found)
+        if (f) return true;
     return false;
 }
 

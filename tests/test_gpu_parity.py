@@ -331,6 +331,26 @@ def test_coincident_faces_keep_the_reference_tie_rule(cornell_like, monkeypatch)
         r.close()
 
 
+def test_one_coincident_face_among_many_is_found(scene_dir):
+    """pt_bvh_upload's search for faces on the same three points, on a scene large enough for its threaded
+    path: one copy of one face (corners rotated) among 120 000."""
+    b0 = util.load_bundle(scenes.write_many_lights_standin(scene_dir, rings=200, segments=300, name="ml_120k"))
+    f = b0.scene.faces.copy()
+    assert len(f) > 100000
+    r = core.Renderer(0)
+    try:
+        r.upload(b0.scene, b0.bvh, b0.lst)
+        assert r.walk_tree() == 0  # nothing found: the first launch will time both trees
+        extra = f[54321:54322].copy()
+        extra["vertices"][0] = np.roll(extra["vertices"][0], 1)
+        b = util.Bundle(host.Scene.from_arrays(b0.scene.vertices.copy(), np.concatenate([f, extra]), b0.scene.materials.copy(),
+                                               lights=b0.scene.lights.copy(), camera=b0.scene.camera))
+        r.upload(b.scene, b.bvh, b.lst)
+        assert r.walk_tree() == 2
+    finally:
+        r.close()
+
+
 def test_height_field_of_tiny_triangles(scene_dir, monkeypatch):
     """A height field of triangles a thousandth of the viewing distance long (the shape of BASELINE config 5):
     Moeller-Trumbore accepts a ray that passes close to an edge in BOTH neighbours, so which of two hits at

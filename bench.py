@@ -109,8 +109,13 @@ def main():
     r = core.Renderer(local_rank)
     r.upload(scene, bvh, lst)
     r.configure(WIDTH, HEIGHT, 0.0, (0.0, 0.0, 0.0))
+    # everything that touches the accumulator runs on ONE side stream: the render launches (handed to the
+    # library by handle), the 1/N scaling and the RCCL reduce (torch orders it against the current stream)
+    side = torch.cuda.Stream(device)
+    torch.cuda.set_stream(side)
     acc = torch.zeros(WIDTH * HEIGHT * 3, dtype=torch.float32, device=device)
-    stream = torch.cuda.current_stream(device).cuda_stream
+    stream = side.cuda_stream
+    assert stream != 0
 
     def barrier():
         torch.cuda.synchronize(device)

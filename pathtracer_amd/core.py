@@ -55,10 +55,22 @@ class Renderer:
         """One blocking launch into the library-owned accumulator (src/main.cu:104-106)."""
         _check(self._lib.pt_render_batch(self._ctx, int(seed), int(previous_samples), int(current_samples)))
 
+    @staticmethod
+    def _stream_arg(stream):
+        """None = the context's own stream. A handle of 0 is the legacy default stream (torch's default
+        stream reports 0): in the C ABI a null stream means "the context's own", which is NOT ordered against
+        the default stream, so passing 0 here would silently launch unordered. Refused: use a
+        torch.cuda.Stream (its .cuda_stream is non-zero), or stream=None plus synchronize()."""
+        if stream is None:
+            return None
+        if int(stream) == 0:
+            raise ValueError("stream handle 0 (the default stream) cannot be passed through the C ABI: "
+                             "use a torch.cuda.Stream, or stream=None and Renderer.synchronize()")
+        return C.c_void_p(int(stream))
+
     def render_batch_into(self, device_ptr, seed, previous_samples, current_samples, stream=None):
         """Asynchronous launch into a caller-owned device buffer (data_ptr of a torch tensor)."""
-        _check(self._lib.pt_render_batch_into(self._ctx, C.c_void_p(int(device_ptr)),
-                                              C.c_void_p(int(stream)) if stream else None,
+        _check(self._lib.pt_render_batch_into(self._ctx, C.c_void_p(int(device_ptr)), self._stream_arg(stream),
                                               int(seed), int(previous_samples), int(current_samples)))
 
     def render(self, seed, samples, samples_every_update):

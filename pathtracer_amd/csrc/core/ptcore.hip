@@ -8,12 +8,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "kernel.h"
-#include "queue.h"
 #include "layout.h"
 #include "ptcore.h"
 
@@ -46,11 +46,17 @@ template <typename T> struct DeviceArray {
         ptr = nullptr;
         count = 0;
     }
-    int upload(const T *src, size_t n) {
+    // (count is recorded only once the allocation has succeeded: a failed call leaves an empty array,
+    // so the next call with the same size allocates again instead of trusting a null pointer)
+    int resize(size_t n) {
         release();
-        count = n;
         size_t sz = (n ? n : 1) * sizeof(T); // never a null device pointer
         HIP_TRY(hipMalloc((void **)&ptr, sz));
+        count = n;
+        return 0;
+    }
+    int upload(const T *src, size_t n) {
+        if (resize(n)) return 1;
         if (n) HIP_TRY(hipMemcpy(ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
         return 0;
     }
@@ -215,13 +221,9 @@ struct pt_context {
     DeviceArray<uint32_t> tile_rng;                        // 8 words per tile
     bool order_valid = false;                    // tile_order holds a permutation for this resolution
     int tile_rows = 8;                           // render_kernel's tile is 8 x tile_rows pixels (8 or 16)
-
-    // queue formulation (queue.h): path state of every pixel slot, hits, two live lists, counters
-    DeviceArray<float4> q_state, q_hit;
-    DeviceArray<uint32_t> q_list0, q_list1, q_cnt;
-    uint32_t *h_cnt = nullptr; // pinned copy of q_cnt
-    int walk_grid = 0;         // resident waves of the persistent walk kernel
-    bool use_queue = false;    // PT_KERNEL=queue at pt_create
+    int cus = 0;                                 // compute units of the device
+    uint64_t serial = 0;                         // unique per context; with `epoch` it names an uploaded scene
+    uint64_t epoch = 0;                          // bumped by every upload
 
     bool have_scene = false, have_bvh = false, have_lst = false, have_cfg = false;
     uint32_t face_count = 0, light_count = 0;
@@ -249,41 +251,61 @@ int ready(pt_context *ctx) {
     return 0;
 }
 
-void set_launch(pt_context *ctx, int seed, int prev, int cur, int jitter) {
+void set_launch(KernelParams &P, int seed, int prev, int cur, int jitter) {
     uint64_t s = (uint64_t)(int64_t)seed; // config_t::seed is int, widened to uint64_t (renderer.cu:374)
-    ctx->P.seed_lo = (uint32_t)s;
-    ctx->P.seed_hi = (uint32_t)(s >> 32);
-    ctx->P.previous_samples = prev;
-    ctx->P.current_samples = cur;
-    ctx->P.jitter = jitter;
-    ctx->P.tile_order = nullptr; // launch_render opts in
-    ctx->P.tile_cost = nullptr;
+    P.seed_lo = (uint32_t)s;
+    P.seed_hi = (uint32_t)(s >> 32);
+    P.previous_samples = prev;
+    P.current_samples = cur;
+    P.jitter = jitter;
+    P.tile_order = nullptr; // launch_render opts in
+    P.tile_cost = nullptr;
 }
 
 // PT_LPT=0 in the environment keeps the static tile order (A/B measurements)
 const bool g_lpt = []() { const char *e = getenv("PT_LPT"); return !(e && e[0] == '0'); }();
 
-// Tiles of render_kernel: 8 x tile_rows pixels, one per wave.
-void render_tiles(const pt_context *ctx, uint32_t *ntx, uint32_t *nty) {
-    *ntx = ((uint32_t)ctx->P.width + 7u) / 8u;
-    *nty = ((uint32_t)ctx->P.height + (uint32_t)ctx->tile_rows - 1u) / (uint32_t)ctx->tile_rows;
+// 8 or 16 pixel rows per tile (see pt_configure). PT_TILE_ROWS in the environment forces one.
+int pick_tile_rows(int width, int height, int cus) {
+    size_t tiles16 = (size_t)((width + 7) / 8) * (size_t)((height + 15) / 16);
+    size_t slots = (size_t)cus * 4 * PT_MIN_WAVES;
+    int rows = tiles16 >= 8 * slots ? 16 : 8;
+    if (const char *e = getenv("PT_TILE_ROWS")) rows = atoi(e) == 16 ? 16 : 8;
+    return rows;
+}
+
+// The per-tile scratch of a launch: device memory beyond its inputs and its image. pt_configure allocates
+// one set per context.
+struct TileScratch {
+    uint32_t *rng;   // [tiles][8]: RNG state of each tile's first pixel for this launch's seed
+    uint32_t *cost;  // [tiles]: ticks the tile kept its wave slot (written by the render launch)
+    uint32_t *key;   // [tiles]: sort keys of launch_rank
+    uint32_t *order; // [tiles]: launch order of the next launch
+    int rows;        // the tile is 8 x rows pixels
+    bool order_valid; // `order` holds a permutation for this scene, resolution and tile shape
+};
+
+// Tiles of render_kernel: 8 x rows pixels, one per wave.
+void render_tiles(const KernelParams &P, int rows, uint32_t *ntx, uint32_t *nty) {
+    *ntx = ((uint32_t)P.width + 7u) / 8u;
+    *nty = ((uint32_t)P.height + (uint32_t)rows - 1u) / (uint32_t)rows;
 }
 
 // Ranks the tiles by the cost the launch before it recorded (same stream, so ordered after it).
-void launch_rank(pt_context *ctx, hipStream_t st) {
+void launch_rank(const KernelParams &P, TileScratch &ts, hipStream_t st) {
     if (!g_lpt) return;
     uint32_t ntx, nty;
-    render_tiles(ctx, &ntx, &nty);
+    render_tiles(P, ts.rows, &ntx, &nty);
     uint32_t n = ntx * nty;
     if (n >= (1u << 24)) return; // keys hold the static position in 24 bits; larger images keep the static order
     dim3 grid((n + 255u) / 256u), block(256);
-    hipLaunchKernelGGL(tile_key_kernel, grid, block, 0, st, ctx->tile_cost.ptr, ctx->tile_key.ptr, n, ntx, nty);
+    hipLaunchKernelGGL(tile_key_kernel, grid, block, 0, st, ts.cost, ts.key, n, ntx, nty);
     // rank of every key among all keys (O(n^2) compares spread over n/64 x 16 blocks), then the scatter;
-    // tile_cost is free once the keys exist and holds the ranks
-    (void)hipMemsetAsync(ctx->tile_cost.ptr, 0, (size_t)n * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(tile_rank_kernel, dim3((n + 63u) / 64u, 16), dim3(64), 0, st, ctx->tile_key.ptr, ctx->tile_cost.ptr, n);
-    hipLaunchKernelGGL(tile_order_kernel, dim3((n + 63u) / 64u), dim3(64), 0, st, ctx->tile_cost.ptr, ctx->tile_order.ptr, n);
-    ctx->order_valid = true;
+    // the cost array is free once the keys exist and holds the ranks
+    (void)hipMemsetAsync(ts.cost, 0, (size_t)n * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(tile_rank_kernel, dim3((n + 63u) / 64u, 16), dim3(64), 0, st, ts.key, ts.cost, n);
+    hipLaunchKernelGGL(tile_order_kernel, dim3((n + 63u) / 64u), dim3(64), 0, st, ts.cost, ts.order, n);
+    ts.order_valid = true;
 }
 
 dim3 grid_of(const pt_context *ctx) {
@@ -292,134 +314,72 @@ dim3 grid_of(const pt_context *ctx) {
     return dim3((waves + per_block - 1) / per_block);
 }
 
-// PT_KERNEL=queue (read at pt_create) selects the queue formulation of queue.h. It is bit-identical
-// and 3x slower (one device-wide barrier per path vertex, each as long as the longest walk), so the
-// default stays render_kernel; kept as the measured baseline for a barrier-free scheduler.
-
-int queue_alloc(pt_context *ctx) {
-    size_t tiles = (size_t)((ctx->P.width + 7) / 8) * (size_t)((ctx->P.height + 7) / 8), slots = tiles * 64;
-    if (ctx->q_hit.count == slots) return 0;
-    ctx->q_state.release(); ctx->q_hit.release(); ctx->q_list0.release(); ctx->q_list1.release(); ctx->q_cnt.release();
-    ctx->q_state.count = slots * qChunks;
-    ctx->q_hit.count = slots;
-    ctx->q_list0.count = ctx->q_list1.count = slots;
-    ctx->q_cnt.count = 4;
-    HIP_TRY(hipMalloc((void **)&ctx->q_state.ptr, ctx->q_state.bytes()));
-    HIP_TRY(hipMalloc((void **)&ctx->q_hit.ptr, ctx->q_hit.bytes()));
-    HIP_TRY(hipMalloc((void **)&ctx->q_list0.ptr, ctx->q_list0.bytes()));
-    HIP_TRY(hipMalloc((void **)&ctx->q_list1.ptr, ctx->q_list1.bytes()));
-    HIP_TRY(hipMalloc((void **)&ctx->q_cnt.ptr, ctx->q_cnt.bytes()));
-    if (!ctx->h_cnt) HIP_TRY(hipHostMalloc((void **)&ctx->h_cnt, 4 * sizeof(uint32_t), hipHostMallocDefault));
-    if (!ctx->walk_grid) {
-        int per_cu = 0, cus = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, queue_walk_kernel<32>, 64, 0));
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-        ctx->walk_grid = per_cu * cus;
-        if (ctx->walk_grid <= 0) return fail("queue_alloc: no occupancy for the walk kernel");
-    }
-    return 0;
-}
-
-// One batch with the queue kernels. Blocks the host between groups of iterations (it has to
-// learn when the last pixel finished); the stream is idle when it returns.
-int render_queue(pt_context *ctx, float *img, hipStream_t st) {
-    if (queue_alloc(ctx)) return 1;
-    QueueParams Q;
-    Q.state = ctx->q_state.ptr;
-    Q.hit = ctx->q_hit.ptr;
-    Q.list[0] = ctx->q_list0.ptr;
-    Q.list[1] = ctx->q_list1.ptr;
-    Q.cnt = ctx->q_cnt.ptr;
-    Q.slots = (uint32_t)ctx->q_hit.count;
-    ctx->P.tile_order = nullptr;
-    ctx->P.tile_cost = nullptr;
-    const KernelParams &P = ctx->P;
-    HIP_TRY(hipMemsetAsync(Q.cnt, 0, 4 * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(queue_init_kernel, dim3(Q.slots / 64), dim3(64), 0, st, P, Q);
-    uint32_t live = (uint32_t)P.width * (uint32_t)P.height; // upper bound on the live pixels, refreshed per group
-    int cur = 0;
-    const int group = 16;
-    while (live != 0) {
-        for (int k = 0; k < group; k++) {
-            uint32_t blocks = (live + 63u) / 64u;
-            uint32_t wgrid = blocks < (uint32_t)ctx->walk_grid ? blocks : (uint32_t)ctx->walk_grid;
-            if (ctx->stack_need <= 32)
-                hipLaunchKernelGGL((queue_walk_kernel<32>), dim3(wgrid), dim3(64), 0, st, P, Q, cur);
-            else
-                hipLaunchKernelGGL((queue_walk_kernel<64>), dim3(wgrid), dim3(64), 0, st, P, Q, cur);
-            hipLaunchKernelGGL(queue_shade_kernel, dim3(blocks), dim3(64), 0, st, P, Q, cur);
-            cur ^= 1;
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ctx->h_cnt, Q.cnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        live = ctx->h_cnt[cur];
-    }
-    hipLaunchKernelGGL(queue_final_kernel, dim3(Q.slots / 64), dim3(64), 0, st, P, Q, img);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 // Per-tile RNG base states for this launch's seed (ordered before the render launch on its stream).
-void launch_tile_rng(pt_context *ctx, uint32_t ntx, uint32_t nty, hipStream_t st) {
-    ctx->P.tile_rng = ctx->tile_rng.ptr;
-    hipLaunchKernelGGL(tile_rng_kernel, dim3((ntx * nty + kTileRngLanes - 1u) / kTileRngLanes), dim3(64), 0, st, ctx->P, ntx, nty,
-                       (uint32_t)ctx->tile_rows);
+void launch_tile_rng(KernelParams &P, const TileScratch &ts, uint32_t ntx, uint32_t nty, hipStream_t st) {
+    P.tile_rng = ts.rng;
+    hipLaunchKernelGGL(tile_rng_kernel, dim3((ntx * nty + kTileRngLanes - 1u) / kTileRngLanes), dim3(64), 0, st, P, ntx, nty,
+                       (uint32_t)ts.rows);
 }
 
 template <bool COUNT, int ROWS, bool WIDE>
-void launch_render_as(pt_context *ctx, dim3 grid, float *img, unsigned long long *counters, hipStream_t st) {
+void launch_render_as(const pt_context *ctx, const KernelParams &P, dim3 grid, float *img, unsigned long long *counters, hipStream_t st) {
     const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
     if (need <= 32)
-        hipLaunchKernelGGL((render_kernel<COUNT, 32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
+        hipLaunchKernelGGL((render_kernel<COUNT, 32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P, img, counters);
     else if (need <= 40)
-        hipLaunchKernelGGL((render_kernel<COUNT, 40, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
+        hipLaunchKernelGGL((render_kernel<COUNT, 40, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P, img, counters);
     else if (need <= 48)
-        hipLaunchKernelGGL((render_kernel<COUNT, 48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
+        hipLaunchKernelGGL((render_kernel<COUNT, 48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P, img, counters);
     else
-        hipLaunchKernelGGL((render_kernel<COUNT, 64, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P, img, counters);
+        hipLaunchKernelGGL((render_kernel<COUNT, 64, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P, img, counters);
 }
 
-template <bool COUNT> void launch_render(pt_context *ctx, float *img, unsigned long long *counters, hipStream_t st) {
+template <bool COUNT>
+void launch_render(const pt_context *ctx, KernelParams &P, const TileScratch &ts, bool wide, float *img, unsigned long long *counters,
+                   hipStream_t st) {
     uint32_t ntx, nty;
-    render_tiles(ctx, &ntx, &nty);
+    render_tiles(P, ts.rows, &ntx, &nty);
     dim3 grid(ntx * nty);
-    ctx->P.tile_order = (ctx->order_valid && g_lpt) ? ctx->tile_order.ptr : nullptr;
-    ctx->P.tile_cost = g_lpt ? ctx->tile_cost.ptr : nullptr;
-    launch_tile_rng(ctx, ntx, nty, st);
-    const bool wide = ctx->walk_tree == 4;
-    if (ctx->tile_rows == 16) {
-        if (wide) launch_render_as<COUNT, 16, true>(ctx, grid, img, counters, st);
-        else launch_render_as<COUNT, 16, false>(ctx, grid, img, counters, st);
+    P.tile_order = (ts.order_valid && g_lpt) ? ts.order : nullptr;
+    P.tile_cost = g_lpt ? ts.cost : nullptr;
+    launch_tile_rng(P, ts, ntx, nty, st);
+    if (ts.rows == 16) {
+        if (wide) launch_render_as<COUNT, 16, true>(ctx, P, grid, img, counters, st);
+        else launch_render_as<COUNT, 16, false>(ctx, P, grid, img, counters, st);
     } else {
-        if (wide) launch_render_as<COUNT, 8, true>(ctx, grid, img, counters, st);
-        else launch_render_as<COUNT, 8, false>(ctx, grid, img, counters, st);
+        if (wide) launch_render_as<COUNT, 8, true>(ctx, P, grid, img, counters, st);
+        else launch_render_as<COUNT, 8, false>(ctx, P, grid, img, counters, st);
     }
 }
 
-template <int ROWS, bool WIDE> void launch_probe_as(pt_context *ctx, dim3 grid, hipStream_t st) {
+template <int ROWS, bool WIDE> void launch_probe_as(const pt_context *ctx, const KernelParams &P, dim3 grid, hipStream_t st) {
     const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
-    if (need <= 32) hipLaunchKernelGGL((cost_probe_kernel<32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
-    else if (need <= 40) hipLaunchKernelGGL((cost_probe_kernel<40, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
-    else if (need <= 48) hipLaunchKernelGGL((cost_probe_kernel<48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
-    else hipLaunchKernelGGL((cost_probe_kernel<64, ROWS, WIDE>), grid, dim3(kBlock), 0, st, ctx->P);
+    if (need <= 32) hipLaunchKernelGGL((cost_probe_kernel<32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P);
+    else if (need <= 40) hipLaunchKernelGGL((cost_probe_kernel<40, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P);
+    else if (need <= 48) hipLaunchKernelGGL((cost_probe_kernel<48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P);
+    else hipLaunchKernelGGL((cost_probe_kernel<64, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P);
 }
 
 // Short launch without an image: records the tile costs (see pt_render_batch_into).
-void launch_probe(pt_context *ctx, hipStream_t st, bool wide) {
+void launch_probe(const pt_context *ctx, KernelParams &P, const TileScratch &ts, hipStream_t st, bool wide) {
     uint32_t ntx, nty;
-    render_tiles(ctx, &ntx, &nty);
+    render_tiles(P, ts.rows, &ntx, &nty);
     dim3 grid(ntx * nty);
-    ctx->P.tile_order = nullptr;
-    ctx->P.tile_cost = ctx->tile_cost.ptr;
-    launch_tile_rng(ctx, ntx, nty, st);
-    if (ctx->tile_rows == 16) {
-        if (wide) launch_probe_as<16, true>(ctx, grid, st);
-        else launch_probe_as<16, false>(ctx, grid, st);
+    P.tile_order = nullptr;
+    P.tile_cost = ts.cost;
+    launch_tile_rng(P, ts, ntx, nty, st);
+    if (ts.rows == 16) {
+        if (wide) launch_probe_as<16, true>(ctx, P, grid, st);
+        else launch_probe_as<16, false>(ctx, P, grid, st);
     } else {
-        if (wide) launch_probe_as<8, true>(ctx, grid, st);
-        else launch_probe_as<8, false>(ctx, grid, st);
+        if (wide) launch_probe_as<8, true>(ctx, P, grid, st);
+        else launch_probe_as<8, false>(ctx, P, grid, st);
     }
+}
+
+// The context's own tile scratch (allocated by pt_configure), and what a launch left in it.
+TileScratch own_scratch(const pt_context *ctx) {
+    return TileScratch{ctx->tile_rng.ptr, ctx->tile_cost.ptr, ctx->tile_key.ptr, ctx->tile_order.ptr, ctx->tile_rows, ctx->order_valid};
 }
 
 } // namespace
@@ -429,6 +389,13 @@ extern "C" const char *pt_last_error(void) { return g_error; }
 namespace {
 int create_resources(pt_context *ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceGetAttribute(&ctx->cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    {
+        static std::mutex mu;
+        static uint64_t next_serial = 0;
+        std::lock_guard<std::mutex> lock(mu);
+        ctx->serial = ++next_serial;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ctx->ev_tune[0]));
     HIP_TRY(hipEventCreate(&ctx->ev_tune[1]));
@@ -458,8 +425,6 @@ extern "C" int pt_create(int device, pt_context **out) {
         pt_destroy(ctx); // keeps the message of the call that failed
         return 1;
     }
-    const char *kernel = getenv("PT_KERNEL");
-    ctx->use_queue = kernel && strcmp(kernel, "queue") == 0;
     *out = ctx;
     return 0;
 }
@@ -485,8 +450,6 @@ extern "C" void pt_destroy(pt_context *ctx) {
     ctx->tile_order.release();
     ctx->tile_key.release();
     ctx->tile_rng.release();
-    ctx->q_state.release(); ctx->q_hit.release(); ctx->q_list0.release(); ctx->q_list1.release(); ctx->q_cnt.release();
-    if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
     for (int i = 0; i < 2; i++)
         if (ctx->ev_tune[i]) (void)hipEventDestroy(ctx->ev_tune[i]);
     for (int i = 0; i < pt_context::kEventRing; i++) {
@@ -522,6 +485,7 @@ extern "C" int pt_scene_upload(pt_context *ctx, const pt_scene_desc *scene) {
 
     // from here on the context holds no complete scene until this call has succeeded
     ctx->have_scene = ctx->have_bvh = ctx->have_lst = false;
+    ctx->epoch++;
     ctx->order_valid = false;
     std::vector<GMaterial> mats;
     bake_shading(*scene, ctx->h_shade, mats);
@@ -593,6 +557,7 @@ extern "C" int pt_bvh_upload(pt_context *ctx, const pt_bvh_node *nodes, uint32_t
     if (!ctx->have_scene) return fail("pt_bvh_upload: call pt_scene_upload first");
     if (!nodes || !indices) return fail("pt_bvh_upload: null argument");
     ctx->have_bvh = false;
+    ctx->epoch++;
     BakedBvh baked;
     std::string err = bake_bvh(ctx->h_shade, nodes, node_count, indices, index_count, baked);
     if (!err.empty()) return fail("pt_bvh_upload: %s", err.c_str());
@@ -629,6 +594,7 @@ extern "C" int pt_lst_upload(pt_context *ctx, const pt_lst_node *nodes, uint32_t
     if (!ctx->have_scene) return fail("pt_lst_upload: call pt_scene_upload first");
     if (count && !nodes) return fail("pt_lst_upload: null argument");
     ctx->have_lst = false;
+    ctx->epoch++;
     std::vector<uint32_t> mult(ctx->face_count, 0);
     for (uint32_t i = 0; i < count; i++) {
         if (nodes[i].type == PT_LST_SOURCE_FACE) {
@@ -702,6 +668,9 @@ extern "C" int pt_configure(pt_context *ctx, const pt_render_config *cfg) {
     if ((uint64_t)cfg->resolution_x * (uint64_t)cfg->resolution_y > 0xFFFFFFFFull)
         return fail("pt_configure: more than 2^32 pixels");
     KernelParams &P = ctx->P;
+    ctx->have_cfg = false; // until every buffer below exists
+    // a tile order belongs to one resolution (two sizes can share a tile count and still map tiles differently)
+    if (P.width != cfg->resolution_x || P.height != cfg->resolution_y) ctx->order_valid = false;
     P.width = cfg->resolution_x;
     P.height = cfg->resolution_y;
     P.clear_color[0] = cfg->world_clear_color.x;
@@ -709,38 +678,21 @@ extern "C" int pt_configure(pt_context *ctx, const pt_render_config *cfg) {
     P.clear_color[2] = cfg->world_clear_color.z;
     P.exposure_scale = powf(2.0f, cfg->output_exposure); // renderer.cu:393
     size_t n = (size_t)P.width * (size_t)P.height * 3;
-    if (ctx->image.count != n) {
-        ctx->image.release();
-        ctx->image.count = n;
-        HIP_TRY(hipMalloc((void **)&ctx->image.ptr, n * sizeof(float)));
-    }
+    if (ctx->image.count != n && ctx->image.resize(n)) return 1;
     HIP_TRY(hipMemset(ctx->image.ptr, 0, n * sizeof(float)));
     // Two pixels per lane (8x16 tiles, pixels swapped between lanes every few samples) keep the lanes of
     // a wave busy to the end of its tile, but halve the number of tiles; that pays only while the
     // launch still has many tiles per wave slot (measured: a loss at 1024^2).
     {
-        int cus = 0;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-        size_t tiles16 = (size_t)((P.width + 7) / 8) * (size_t)((P.height + 15) / 16);
-        size_t slots = (size_t)cus * 4 * PT_MIN_WAVES;
-        int rows = tiles16 >= 8 * slots ? 16 : 8;
-        if (const char *e = getenv("PT_TILE_ROWS")) rows = atoi(e) == 16 ? 16 : 8;
+        int rows = pick_tile_rows(P.width, P.height, ctx->cus);
         if (rows != ctx->tile_rows) ctx->order_valid = false;
         ctx->tile_rows = rows;
     }
     size_t tiles = (size_t)((P.width + 7) / 8) * (size_t)((P.height + 7) / 8);
     if (ctx->tile_cost.count != tiles) {
-        ctx->tile_cost.release();
-        ctx->tile_order.release();
-        ctx->tile_key.release();
-        ctx->tile_rng.release();
-        ctx->tile_rng.count = tiles * 8;
-        HIP_TRY(hipMalloc((void **)&ctx->tile_rng.ptr, ctx->tile_rng.bytes()));
-        ctx->tile_cost.count = ctx->tile_order.count = ctx->tile_key.count = tiles;
-        HIP_TRY(hipMalloc((void **)&ctx->tile_cost.ptr, tiles * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&ctx->tile_key.ptr, tiles * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&ctx->tile_order.ptr, tiles * sizeof(uint32_t)));
         ctx->order_valid = false;
+        if (ctx->tile_rng.resize(tiles * 8) || ctx->tile_cost.resize(tiles) || ctx->tile_key.resize(tiles) || ctx->tile_order.resize(tiles))
+            return 1;
     }
     ctx->have_cfg = true;
     return 0;
@@ -754,55 +706,66 @@ extern "C" int pt_clear_image(pt_context *ctx) {
     return 0;
 }
 
+namespace {
+// One render launch of `P` with its tile scratch `ts` on `st`: the launches around it that record tile
+// costs and rank them, and the HIP events of pt_kernel_ms. may_block: the first launch after an upload may
+// time both trees (blocks the host for about 10 ms); otherwise an untimed choice is made.
+int render_launches(pt_context *ctx, KernelParams &P, TileScratch &ts, float *img, hipStream_t st, bool may_block) {
+    const int current_samples = P.current_samples;
+    const int slot = (int)(ctx->launches % pt_context::kEventRing);
+    HIP_TRY(hipEventRecord(ctx->ev_start[slot], st));
+    if (ctx->walk_tree == 0 && current_samples >= 8 && may_block) {
+        // Which tree walks this scene faster depends on the scene (four-wide: half the node visits, but
+        // fewer lanes stepping together; measured both ways, -12 % .. +7 %). Both give the same hits, so
+        // time a 2-sample launch without an image on each and keep the faster. Blocks the host once per
+        // uploaded tree (about 10 ms).
+        float ms[2] = {0.f, 0.f};
+        P.current_samples = 2;
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipEventRecord(ctx->ev_tune[0], st));
+            launch_probe(ctx, P, ts, st, k == 1);
+            HIP_TRY(hipEventRecord(ctx->ev_tune[1], st));
+            HIP_TRY(hipEventSynchronize(ctx->ev_tune[1]));
+            HIP_TRY(hipEventElapsedTime(&ms[k], ctx->ev_tune[0], ctx->ev_tune[1]));
+        }
+        ctx->walk_tree = ms[1] < ms[0] ? 4 : 2;
+        P.current_samples = current_samples;
+        if (g_lpt && !ts.order_valid) launch_rank(P, ts, st); // the second probe's tile costs order the first batch
+    } else if (ctx->walk_tree == 0 && may_block) {
+        ctx->walk_tree = 2;
+    }
+    // a call that may not block leaves the choice open: untimed, the four-wide tree (it wins on most scenes, and
+    // pt_bvh_upload has already ruled it out where it cannot be used)
+    const bool wide = (ctx->walk_tree == 0 ? 4 : ctx->walk_tree) == 4;
+    if (g_lpt && !ts.order_valid && current_samples >= 8) {
+        // No costs recorded yet for this scene/resolution: a 1-sample launch that writes no pixel
+        // (null image) records them, so that even the first batch is dispatched heaviest first.
+        P.current_samples = 1;
+        launch_probe(ctx, P, ts, st, wide);
+        launch_rank(P, ts, st);
+        P.current_samples = current_samples;
+    }
+    launch_render<false>(ctx, P, ts, wide, img, nullptr, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));
+    launch_rank(P, ts, st);
+    HIP_TRY(hipGetLastError());
+    ctx->launches++;
+    return 0;
+}
+} // namespace
+
 extern "C" int pt_render_batch_into(pt_context *ctx, float *device_img, void *stream, int seed, int previous_samples,
                                     int current_samples) {
     if (ready(ctx)) return 1;
     if (!device_img) return fail("pt_render_batch_into: null image");
     if (current_samples <= 0 || previous_samples < 0) return fail("pt_render_batch: bad sample counts (%d, %d)", previous_samples, current_samples);
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    set_launch(ctx, seed, previous_samples, current_samples, 1);
-    const int slot = (int)(ctx->launches % pt_context::kEventRing);
-    HIP_TRY(hipEventRecord(ctx->ev_start[slot], st));
-    if (ctx->use_queue) {
-        if (render_queue(ctx, device_img, st)) return 1;
-        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));
-    } else {
-        if (ctx->walk_tree == 0 && current_samples >= 8) {
-            // Which tree walks this scene faster depends on the scene (four-wide: half the node visits, but
-            // fewer lanes stepping together; measured both ways, -12 % .. +7 %). Both give the same hits, so
-            // time a 2-sample launch without an image on each and keep the faster. Blocks the host once per
-            // uploaded tree (about 10 ms).
-            float ms[2] = {0.f, 0.f};
-            ctx->P.current_samples = 2;
-            for (int k = 0; k < 2; k++) {
-                HIP_TRY(hipEventRecord(ctx->ev_tune[0], st));
-                launch_probe(ctx, st, k == 1);
-                HIP_TRY(hipEventRecord(ctx->ev_tune[1], st));
-                HIP_TRY(hipEventSynchronize(ctx->ev_tune[1]));
-                HIP_TRY(hipEventElapsedTime(&ms[k], ctx->ev_tune[0], ctx->ev_tune[1]));
-            }
-            ctx->walk_tree = ms[1] < ms[0] ? 4 : 2;
-            ctx->P.current_samples = current_samples;
-            if (g_lpt && !ctx->order_valid) launch_rank(ctx, st); // the second probe's tile costs order the first batch
-        } else if (ctx->walk_tree == 0) {
-            ctx->walk_tree = 2;
-        }
-        if (g_lpt && !ctx->order_valid && current_samples >= 8) {
-            // No costs recorded yet for this scene/resolution: a 1-sample launch that writes no pixel
-            // (null image) records them, so that even the first batch is dispatched heaviest first.
-            ctx->P.current_samples = 1;
-            launch_probe(ctx, st, ctx->walk_tree == 4);
-            launch_rank(ctx, st);
-            ctx->P.current_samples = current_samples;
-        }
-        launch_render<false>(ctx, device_img, nullptr, st);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], st));
-        launch_rank(ctx, st);
-        HIP_TRY(hipGetLastError());
-    }
-    ctx->launches++;
-    return 0;
+    set_launch(ctx->P, seed, previous_samples, current_samples, 1);
+    TileScratch ts = own_scratch(ctx);
+    int rc = render_launches(ctx, ctx->P, ts, device_img, st, true);
+    ctx->order_valid = ts.order_valid;
+    return rc;
 }
 
 extern "C" int pt_render_batch(pt_context *ctx, int seed, int previous_samples, int current_samples) {
@@ -866,7 +829,7 @@ extern "C" int pt_primary_hits(pt_context *ctx, int seed, int jitter, int32_t *h
         (void)hipFree(d_faces);
         return fail("HIP error: %s (pt_primary_hits)", hipGetErrorString(e));
     }
-    set_launch(ctx, seed, 0, 1, jitter);
+    set_launch(ctx->P, seed, 0, 1, jitter);
     if (ctx->bvh_height <= 33)
         hipLaunchKernelGGL((primary_hits_kernel<32>), grid_of(ctx), dim3(kBlock), 0, ctx->stream, ctx->P, d_faces, d_dist);
     else
@@ -884,8 +847,11 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
     if (ready(ctx)) return 1;
     if (!out || current_samples <= 0) return fail("pt_count_batch: bad arguments");
     HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, ctx->counters.bytes(), ctx->stream));
-    set_launch(ctx, seed, 0, current_samples, 1);
-    launch_render<true>(ctx, nullptr, ctx->counters.ptr, ctx->stream);
+    set_launch(ctx->P, seed, 0, current_samples, 1);
+    {
+        TileScratch ts = own_scratch(ctx);
+        launch_render<true>(ctx, ctx->P, ts, ctx->walk_tree == 4, nullptr, ctx->counters.ptr, ctx->stream);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     unsigned long long h[32];
@@ -914,6 +880,5 @@ extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
     if (!ctx) return 0;
     return ctx->nodes.bytes() + ctx->nodes4.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
            ctx->lst.bytes() + ctx->glights.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes() +
-           ctx->tile_cost.bytes() + ctx->tile_key.bytes() + ctx->tile_order.bytes() + ctx->tile_rng.bytes() +
-           ctx->q_state.bytes() + ctx->q_hit.bytes() + ctx->q_list0.bytes() + ctx->q_list1.bytes() + ctx->q_cnt.bytes();
+           ctx->tile_cost.bytes() + ctx->tile_key.bytes() + ctx->tile_order.bytes() + ctx->tile_rng.bytes();
 }

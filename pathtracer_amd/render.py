@@ -28,7 +28,12 @@ def plan_batches(samples, samples_every_update, rank=0, world_size=1):
 
 def render_local(renderer, acc, seed, plan, stream=None):
     """Launches this rank's batches into `acc` (a float32 device tensor of H*W*3). Asynchronous.
-    Returns the number of samples per pixel accumulated."""
+    Returns the number of samples per pixel accumulated.
+
+    Ordering rule: the launches go to `stream` (a non-zero hipStream_t handle, e.g. the .cuda_stream of a
+    torch.cuda.Stream that is current while `acc` is produced and consumed) or, with stream=None, to the
+    context's own non-blocking stream, which NO torch stream is ordered against: then call
+    renderer.synchronize() before touching `acc` (combine() included)."""
     prev = 0
     for _, seed_offset, cur in plan:
         renderer.render_batch_into(acc.data_ptr(), seed + seed_offset, prev, cur, stream)
@@ -53,9 +58,17 @@ def render_sharded(renderer, width, height, seed, samples, samples_every_update,
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     device = device if device is not None else torch.device("cuda", renderer.device)
-    acc = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
     plan = plan_batches(samples, samples_every_update, rank, world)
-    stream = torch.cuda.current_stream(device).cuda_stream
-    local = render_local(renderer, acc, seed, plan, stream)
-    combine(acc, local, samples)
+    # One side stream carries everything that touches the accumulator: its zero fill, the render launches
+    # (handed to the library by handle), the scaling and the reduce (torch orders NCCL work against the
+    # current stream). The caller's stream waits for it at the end.
+    caller = torch.cuda.current_stream(device)
+    side = torch.cuda.Stream(device)
+    side.wait_stream(caller)
+    with torch.cuda.stream(side):
+        acc = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
+        local = render_local(renderer, acc, seed, plan, side.cuda_stream)
+        combine(acc, local, samples)
+    caller.wait_stream(side)
+    acc.record_stream(caller)
     return acc.view(height, width, 3)

@@ -55,7 +55,7 @@ def main():
         print(f"GPU {tree} tree ({ms:.1f} ms per launch): {n} of {diff.size} floats differ from the oracle in bits "
               f"({int(diff.any(axis=2).sum())} pixels, max abs {float(np.abs(np.where(both, gpu - cpu, 0)).max()):.3e}); "
               f"non-finite floats {int((~np.isfinite(gpu)).sum())} / {int((~np.isfinite(cpu)).sum())}", flush=True)
-        bad += n if tree == "binary" else 0
+        bad += n
     return 1 if bad else 0
 
 

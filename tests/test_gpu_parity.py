@@ -392,17 +392,55 @@ def test_two_pixels_per_lane_tiles(cornell_like, monkeypatch):
         r.close()
 
 
-def test_queue_formulation_is_bit_identical(cornell_like, monkeypatch):
-    """csrc/core/queue.h (PT_KERNEL=queue: path state in HBM, walk / shade kernels over a compacted
-    list) computes the same image as the product kernel and the oracle."""
-    monkeypatch.setenv("PT_KERNEL", "queue")
+def test_reconfigure_between_sizes_that_share_a_tile_count(cornell_like, monkeypatch):
+    """16x24 and 24x16 have the same number of 8x8 tiles (6) but map 8x16 tiles differently (2x2 against
+    3x1): the launch order recorded for one is no permutation for the other, so pt_configure must drop it
+    whenever the size changes. Also with one pixel per lane, 48x16 then 16x48."""
+    for rows, sizes in (("16", ((16, 24), (24, 16))), ("8", ((48, 16), (16, 48)))):
+        monkeypatch.setenv("PT_TILE_ROWS", rows)
+        r = core.Renderer(0)
+        try:
+            r.upload(cornell_like.scene, cornell_like.bvh, cornell_like.lst)
+            for w, h in sizes:
+                r.configure(w, h)
+                o = ob.Oracle(cornell_like.scene, cornell_like.bvh, cornell_like.lst, w, h)
+                gpu = r.render(5, 16, 8)  # launches of 8 samples: the tile costs are recorded and ranked
+                _assert_images_match(gpu, o.render(5, 16, 8))
+        finally:
+            r.close()
+
+
+def test_combine_is_ordered_after_the_render_launches(scene_dir):
+    """the scaling + reduce of render.combine must see the finished accumulator. Several
+    1024x1024 batches (tens of ms of kernels in flight) on the side stream render_sharded uses, then
+    combine(acc, local, 2 * local): the result is exactly half the batch-loop image. With the launches on a
+    stream torch does not order against, the scaling would run while the kernels are still blending."""
+    import torch
+    from pathtracer_amd import render
+    b = util.load_bundle(scenes.write_many_lights_standin(scene_dir, rings=60, segments=96, name="ml_order"))
+    w = h = 1024
     r = core.Renderer(0)
     try:
-        w, h = 100, 52  # ragged tiles
-        o = _setup(r, cornell_like, w, h, exposure=0.5)
-        gpu = r.render(4, 7, 3)  # batches of 3, 3, 1
-        cpu = o.render(4, 7, 3)
-        _assert_images_match(gpu, cpu)
+        r.upload(b.scene, b.bvh, b.lst)
+        r.configure(w, h)
+        want = r.render(42, 24, 8)
+        device = torch.device("cuda", 0)
+        side = torch.cuda.Stream(device)
+        with torch.cuda.stream(side):
+            acc = torch.zeros(w * h * 3, dtype=torch.float32, device=device)
+            local = render.render_local(r, acc, 42, render.plan_batches(24, 8), side.cuda_stream)
+            render.combine(acc, local, 2 * local)
+        side.synchronize()
+        got = acc.cpu().numpy().reshape(h, w, 3)
+        assert local == 24
+        assert np.array_equal(util.bits(got), util.bits(want * np.float32(0.5)))
+        # the default stream's handle (0) is refused instead of being taken for "the context's own stream"
+        with pytest.raises(ValueError):
+            r.render_batch_into(acc.data_ptr(), 1, 0, 1, stream=0)
+        # and the whole of render_sharded, called from the default stream
+        img = render.render_sharded(r, w, h, 42, 24, 8)
+        torch.cuda.synchronize()
+        assert np.array_equal(util.bits(img.cpu().numpy()), util.bits(want))
     finally:
         r.close()
 

@@ -111,6 +111,22 @@ int pt_render_batch(pt_context *ctx, int seed, int previous_samples, int current
 int pt_render_batch_into(pt_context *ctx, float *device_img, void *stream, int seed,
                          int previous_samples, int current_samples);
 
+/* NO COUNTERPART IN THE REFERENCE. For callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc. The same launch as pt_render_batch_into,
+ * with two differences: (1) the image size, exposure and clear colour come with the call (pt_configure, whose
+ * job is to allocate, need not have been called, and is not disturbed if it was); (2) the kernels' per-tile
+ * scratch (RNG base states, tile costs, sort keys, launch order: 44 bytes per 8x8 tile) lives in ONE
+ * file-scope static device array of PT_STATIC_MAX_TILES tiles (2.75 MiB) that every GPU the library runs on
+ * holds until the process ends. Calls no hipMalloc / hipFree or other allocating routine and never blocks
+ * the host (no tree timing: a tree not chosen yet is walked four-wide; pixels do not depend on it).
+ * Limit: ceil(x/8) * ceil(y/8) <= PT_STATIC_MAX_TILES (e.g. 2048 x 2048); larger sizes are refused with an
+ * error. All calls on one GPU, from any context, share that GPU's array: calls that overlap on one GPU
+ * (two streams, two contexts, two threads) race. device_img: caller-owned device buffer of
+ * resolution_x * resolution_y * 3 floats; stream as in pt_render_batch_into. */
+#define PT_STATIC_MAX_TILES 65536
+int pt_render_batch_static(pt_context *ctx, float *device_img, void *stream, const pt_render_config *cfg, int seed,
+                           int previous_samples, int current_samples);
+
 /* cudaMemcpy(h_img, d_img, ..., DeviceToHost) — src/main.cu:111. Caller-owned
  * host buffer of resolution_x*resolution_y*3 floats, row 0 = bottom row as in
  * the reference (the flip happens at PNG write, src/image.cu:94). */

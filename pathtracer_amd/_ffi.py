@@ -184,6 +184,7 @@ def core_lib():
     L.pt_configure.argtypes = [C.c_void_p, C.POINTER(RenderConfig)]
     L.pt_render_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.pt_render_batch_into.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.pt_render_batch_static.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RenderConfig), C.c_int, C.c_int, C.c_int]
     L.pt_read_image.argtypes = [C.c_void_p, C.c_void_p]
     L.pt_clear_image.argtypes = [C.c_void_p]
     L.pt_synchronize.argtypes = [C.c_void_p]

@@ -73,6 +73,14 @@ class Renderer:
         _check(self._lib.pt_render_batch_into(self._ctx, C.c_void_p(int(device_ptr)), self._stream_arg(stream),
                                               int(seed), int(previous_samples), int(current_samples)))
 
+    def render_batch_static(self, device_ptr, width, height, seed, previous_samples, current_samples, stream=None,
+                            exposure=0.0, clear_color=(0.0, 0.0, 0.0)):
+        """pt_render_batch_static: the same launch with its tile scratch in the library's static device
+        array (no allocation, no host block); image size, exposure and clear colour come with the call."""
+        cfg = _ffi.RenderConfig(int(width), int(height), float(exposure), _ffi.Vec3(*[float(c) for c in clear_color]))
+        _check(self._lib.pt_render_batch_static(self._ctx, C.c_void_p(int(device_ptr)), self._stream_arg(stream), C.byref(cfg),
+                                                int(seed), int(previous_samples), int(current_samples)))
+
     def render(self, seed, samples, samples_every_update):
         """The batch loop of src/main.cu:101-133 without the per-batch PNG: seed+1 per batch."""
         self.clear()

@@ -275,7 +275,7 @@ int pick_tile_rows(int width, int height, int cus) {
 }
 
 // The per-tile scratch of a launch: device memory beyond its inputs and its image. pt_configure allocates
-// one set per context.
+// one set per context; pt_render_batch_static points it into the file-scope static array instead.
 struct TileScratch {
     uint32_t *rng;   // [tiles][8]: RNG state of each tile's first pixel for this launch's seed
     uint32_t *cost;  // [tiles]: ticks the tile kept its wave slot (written by the render launch)
@@ -382,6 +382,34 @@ TileScratch own_scratch(const pt_context *ctx) {
     return TileScratch{ctx->tile_rng.ptr, ctx->tile_cost.ptr, ctx->tile_key.ptr, ctx->tile_order.ptr, ctx->tile_rows, ctx->order_valid};
 }
 
+// ---- static scratch (pt_render_batch_static) ---------------------------------------------------
+// One array per GPU, held until the process ends: per-tile RNG base states (8 words), cost, key and order
+// (one word each) for up to PT_STATIC_MAX_TILES tiles of 8x8 pixels. In HOST code the array's name is only
+// a handle for hipGetSymbolAddress: pt_create asks for its device address once per device, with that device
+// current, and every use below goes through that pointer.
+constexpr size_t kStaticWordsPerTile = 11;
+static __device__ __align__(256) uint32_t scratch[(size_t)PT_STATIC_MAX_TILES * kStaticWordsPerTile];
+
+constexpr int kMaxDevices = 64;
+struct StaticScratch {
+    uint32_t *ptr = nullptr; // device address of `scratch` on this device
+    // what the last pt_render_batch_static call on this device left in the order array
+    bool order_valid = false;
+    uint64_t serial = 0, epoch = 0;
+    int width = 0, height = 0, rows = 0;
+};
+StaticScratch g_static[kMaxDevices];
+
+int static_scratch_init(int device) { // device is current
+    if (device < 0 || device >= kMaxDevices) return fail("pt_create: device %d beyond the %d the static scratch table holds", device, kMaxDevices);
+    if (g_static[device].ptr) return 0;
+    uint32_t *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail("pt_create: hipGetSymbolAddress returned a null address for the static scratch");
+    g_static[device].ptr = ptr;
+    return 0;
+}
+
 } // namespace
 
 extern "C" const char *pt_last_error(void) { return g_error; }
@@ -395,6 +423,7 @@ int create_resources(pt_context *ctx) {
         static uint64_t next_serial = 0;
         std::lock_guard<std::mutex> lock(mu);
         ctx->serial = ++next_serial;
+        if (static_scratch_init(ctx->device)) return 1; // once per device, with that device current
     }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ctx->ev_tune[0]));
@@ -765,6 +794,60 @@ extern "C" int pt_render_batch_into(pt_context *ctx, float *device_img, void *st
     TileScratch ts = own_scratch(ctx);
     int rc = render_launches(ctx, ctx->P, ts, device_img, st, true);
     ctx->order_valid = ts.order_valid;
+    return rc;
+}
+
+extern "C" int pt_render_batch_static(pt_context *ctx, float *device_img, void *stream, const pt_render_config *cfg, int seed,
+                                      int previous_samples, int current_samples) {
+    if (bind(ctx)) return 1;
+    if (!ctx->have_scene) return fail("pt_scene_upload has not been called");
+    if (!ctx->have_bvh) return fail("pt_bvh_upload has not been called");
+    if (!ctx->have_lst) return fail("pt_lst_upload has not been called");
+    if (!device_img) return fail("pt_render_batch_static: null image");
+    if (!cfg) return fail("pt_render_batch_static: null config");
+    if (current_samples <= 0 || previous_samples < 0) return fail("pt_render_batch_static: bad sample counts (%d, %d)", previous_samples, current_samples);
+    if (cfg->resolution_x <= 0 || cfg->resolution_y <= 0) return fail("pt_render_batch_static: empty image");
+    const uint64_t tiles = (uint64_t)(((int64_t)cfg->resolution_x + 7) / 8) * (uint64_t)(((int64_t)cfg->resolution_y + 7) / 8);
+    if (tiles > (uint64_t)PT_STATIC_MAX_TILES)
+        return fail("pt_render_batch_static: %d x %d pixels are %llu tiles of 8x8, the static scratch holds %d (use pt_configure + "
+                    "pt_render_batch_into for larger images)", cfg->resolution_x, cfg->resolution_y, (unsigned long long)tiles, PT_STATIC_MAX_TILES);
+    StaticScratch &g = g_static[ctx->device];
+    if (!g.ptr) return fail("pt_render_batch_static: no static scratch address for device %d", ctx->device);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+
+    // the launch parameters of this call: the scene's, with the call's own image size, exposure and clear colour
+    KernelParams P = ctx->P;
+    P.width = cfg->resolution_x;
+    P.height = cfg->resolution_y;
+    P.clear_color[0] = cfg->world_clear_color.x;
+    P.clear_color[1] = cfg->world_clear_color.y;
+    P.clear_color[2] = cfg->world_clear_color.z;
+    P.exposure_scale = powf(2.0f, cfg->output_exposure); // renderer.cu:393
+    set_launch(P, seed, previous_samples, current_samples, 1);
+
+    // the tile arrays inside the static array: RNG states first (8 words per tile), then cost, key, order
+    TileScratch ts;
+    ts.rng = g.ptr;
+    ts.cost = g.ptr + (size_t)PT_STATIC_MAX_TILES * 8;
+    ts.key = ts.cost + PT_STATIC_MAX_TILES;
+    ts.order = ts.key + PT_STATIC_MAX_TILES;
+    ts.rows = pick_tile_rows(P.width, P.height, ctx->cus);
+    // Every call on this GPU shares the array, which keeps the last call's contents. The order array is the only
+    // part read before it is written: it counts only if the last call left it for this very scene, size and
+    // tile shape. (Costs are written by every launch before they are read; keys likewise; the ranking clears
+    // the cost array itself before it accumulates ranks into it.)
+    ts.order_valid = g.order_valid && g.serial == ctx->serial && g.epoch == ctx->epoch && g.width == P.width && g.height == P.height &&
+                     g.rows == ts.rows;
+    g.order_valid = false; // until this call's launches are in the stream
+    int rc = render_launches(ctx, P, ts, device_img, st, false);
+    if (rc == 0) {
+        g.order_valid = ts.order_valid;
+        g.serial = ctx->serial;
+        g.epoch = ctx->epoch;
+        g.width = P.width;
+        g.height = P.height;
+        g.rows = ts.rows;
+    }
     return rc;
 }
 

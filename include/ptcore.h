@@ -142,9 +142,15 @@ int pt_synchronize(pt_context *ctx);
 int pt_rng_stream(pt_context *ctx, uint64_t seed, uint64_t subsequence, uint32_t *host_out, int n);
 
 /* Face id hit by the first camera ray of every pixel (-1 = miss) and its
- * distance; jitter = 0 zeroes the Box-Muller offsets. Host buffers of
- * resolution_x*resolution_y entries; distances may be NULL. */
-int pt_primary_hits(pt_context *ctx, int seed, int jitter, int32_t *host_face_ids, float *host_distances);
+ * distance (1e30 on a miss); jitter = 0 zeroes the Box-Muller offsets. Walked by the
+ * same walker as the render launches (sliced speculative walk + sequential
+ * start-over), on the tree `tree` names: 2 = binary, 4 = four-wide, 0 = the one
+ * render launches use (binary if not chosen yet). *redone_walks (may be NULL) =
+ * rays that found two candidates within rounding of each other and were walked
+ * again in the reference's order: the count of epsilon ties of this launch.
+ * Host buffers of resolution_x*resolution_y entries; distances may be NULL. */
+int pt_primary_hits(pt_context *ctx, int seed, int jitter, int tree, int32_t *host_face_ids, float *host_distances,
+                    uint64_t *redone_walks);
 
 /* Runs the instrumented variant of one batch (does not touch the image). */
 int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt_counters *out);

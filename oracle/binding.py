@@ -23,6 +23,15 @@ class Inputs(C.Structure):  # orc_inputs
     ]
 
 
+class NonfiniteDiag(C.Structure):  # orc_nonfinite_diag
+    _fields_ = [(n, C.c_int32) for n in ("found", "where", "sample", "bounce", "face", "material")] + \
+               [(n, C.c_float) for n in ("roughness", "metallic", "h_z", "pdf")] + \
+               [(n, C.c_float * 3) for n in ("wo_ts", "w_ts", "f_cos", "tangent", "bitangent", "normal", "ray_dir")]
+
+    def as_dict(self):
+        return {n: (list(getattr(self, n)) if hasattr(getattr(self, n), "__len__") else getattr(self, n)) for n, _ in self._fields_}
+
+
 _lib = None
 
 
@@ -44,6 +53,7 @@ def lib():
         L.orc_rng_sequence_jump_matrix.argtypes = [C.c_int, C.c_void_p]
         L.orc_rng_sequence_jump_matrix.restype = None
         L.orc_primary_hits.argtypes = [C.POINTER(Inputs), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_find_nonfinite.argtypes = [C.POINTER(Inputs), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(NonfiniteDiag)]
         L.orc_sample_texture.argtypes = [C.POINTER(_ffi.Texture), C.c_float, C.c_float, C.c_void_p]
         L.orc_sample_texture.restype = None
         L.orc_logf.argtypes = [C.c_float]
@@ -98,6 +108,11 @@ class Oracle:
             done += cur
             seed += 1
         return img
+
+    def find_nonfinite(self, seed, current_samples, px, py):
+        """Where pixel (px, py) of that batch first turns non-finite (None if it does not)."""
+        d = NonfiniteDiag()
+        return d.as_dict() if lib().orc_find_nonfinite(C.byref(self.inputs), seed, current_samples, px, py, C.byref(d)) else None
 
     def primary_hits(self, seed, jitter=True):
         ids = np.zeros((self.height, self.width), np.int32)

@@ -263,7 +263,11 @@ struct Ctx {
     const pt_scene_desc *sc;
     Rng rng;
     orc_counters n{};
+    orc_nonfinite_diag *diag = nullptr; // orc_find_nonfinite only
+    int sample_index = 0;
 };
+
+inline bool finite3(V3 a) { return std::isfinite(a.x) && std::isfinite(a.y) && std::isfinite(a.z); }
 
 // intersect.cu:12-81, non-culling branch
 int moeller_trumbore(const Ray &ray, V3 v0, V3 v1, V3 v2, float *t, float *u, float *v) {
@@ -590,7 +594,32 @@ inline void project_equirect(V3 d, float *u, float *v) {
 V3 integrate_Li(Ctx &c, Ray ray) {
     V3 light = mk(0, 0, 0);
     V3 throughput = mk(1, 1, 1);
+    int bounce = -1;
+    // diagnostics (orc_find_nonfinite): the first path vertex at which a term stops being finite
+    auto note = [&](int where, const Hit &hit, V3 wo_ts, V3 w_ts, V3 f_cos, float p) {
+        orc_nonfinite_diag *d = c.diag;
+        if (!d || d->found) return;
+        d->found = 1;
+        d->where = where;
+        d->sample = c.sample_index;
+        d->bounce = bounce;
+        d->face = hit.faceIndex;
+        d->material = (int)(hit.mat - c.sc->materials);
+        d->roughness = hit.brdf.roughness;
+        d->metallic = hit.brdf.metallic;
+        V3 h = unit(w_ts + wo_ts);
+        d->h_z = h.z;
+        d->pdf = p;
+        const V3 cols[3] = {mk(hit.tangentBasis.m[0][0], hit.tangentBasis.m[1][0], hit.tangentBasis.m[2][0]),
+                            mk(hit.tangentBasis.m[0][1], hit.tangentBasis.m[1][1], hit.tangentBasis.m[2][1]),
+                            mk(hit.tangentBasis.m[0][2], hit.tangentBasis.m[1][2], hit.tangentBasis.m[2][2])};
+        const V3 src[6] = {wo_ts, w_ts, f_cos, cols[0], cols[1], cols[2]};
+        float *dst[6] = {d->wo_ts, d->w_ts, d->f_cos, d->tangent, d->bitangent, d->normal};
+        for (int k = 0; k < 6; k++) { dst[k][0] = src[k].x; dst[k][1] = src[k].y; dst[k][2] = src[k].z; }
+        d->ray_dir[0] = ray.r.x; d->ray_dir[1] = ray.r.y; d->ray_dir[2] = ray.r.z;
+    };
     for (;;) {
+        bounce++;
         Hit hit;
         intersect(c, ray, hit);
         if (!hit.has_hit) {
@@ -625,6 +654,7 @@ V3 integrate_Li(Ctx &c, Ray ray) {
             V3 direct = f_cos * lss.radiance;
             float weight = lss.p_lss / (lss.p_lss + p_brdf);
             light = light + ((weight / lss.p_lss) * throughput) * direct;
+            if (c.diag && !finite3(light)) note(1, hit, wo_ts, l_ts, f_cos, lss.p_lss);
         }
 
         V3 wi = sphere_sample_uniform(c.rng);
@@ -638,6 +668,7 @@ V3 integrate_Li(Ctx &c, Ray ray) {
         float p_direct = evaluate_direct_p(c, ray, hit);
         float weight = pdf / (p_direct + pdf);
         throughput = throughput * (f_cos * (weight / (pdf * rr_prob)));
+        if (c.diag && !finite3(throughput)) note(2, hit, wo_ts, wi, f_cos, p_direct);
     }
     return light;
 }
@@ -739,6 +770,26 @@ extern "C" int orc_render_batch(const orc_inputs *in, int seed, int prev, int cu
                                 orc_counters *counters) {
     if (!in) return 1;
     return orc_render_rows(in, seed, prev, cur, img, 0, in->cfg.resolution_y, threads, counters);
+}
+
+extern "C" int orc_find_nonfinite(const orc_inputs *in, int seed, int cur, int px, int py, orc_nonfinite_diag *out) {
+    if (!in || !in->scene || !out) return 0;
+    int W = in->cfg.resolution_x, H = in->cfg.resolution_y;
+    memset(out, 0, sizeof(*out));
+    Ctx c;
+    c.in = in;
+    c.sc = in->scene;
+    c.diag = out;
+    rng_init(c.rng, (uint64_t)(int64_t)seed, (uint64_t)(int64_t)(py * W + px));
+    for (int i = 0; i < cur && !out->found; i++) { // render_pixel's loop
+        c.sample_index = i;
+        float sx = (float)px + 0.33f * rng_normal(c.rng);
+        float sy = (float)py + 0.33f * rng_normal(c.rng);
+        float u = (2 * sx - (float)W) / (float)H;
+        float v = (2 * sy - (float)H) / (float)H;
+        (void)integrate_Li(c, camera_ray(in->scene->camera, u, v));
+    }
+    return out->found;
 }
 
 extern "C" void orc_rng_state(uint64_t seed, uint64_t subsequence, uint32_t state[6]) {

@@ -75,6 +75,17 @@ void orc_rng_sequence_jump_matrix(int k, uint32_t out[800]);
  * with `seed`), -1 on a miss. jitter=0 replaces the Box-Muller offsets by 0. */
 int orc_primary_hits(const orc_inputs *in, int seed, int jitter, int32_t *face_ids, float *distances);
 
+/* Diagnostics: replays pixel (px, py) of a batch and reports the first path vertex at which the radiance
+ * (where = 1: the direct term, renderer.cu:333-342) or the throughput (where = 2: the BSDF sample,
+ * renderer.cu:352-355) stops being finite. w_ts is the incident direction of that term in tangent space,
+ * h_z the z of the half vector brdf.cu:14 evaluates GGX at. Returns 1 if such a vertex was found. */
+typedef struct {
+    int32_t found, where, sample, bounce, face, material;
+    float roughness, metallic, h_z, pdf;
+    float wo_ts[3], w_ts[3], f_cos[3], tangent[3], bitangent[3], normal[3], ray_dir[3];
+} orc_nonfinite_diag;
+int orc_find_nonfinite(const orc_inputs *in, int seed, int current_samples, int px, int py, orc_nonfinite_diag *out);
+
 /* Software texture fetch, exposed for unit tests. */
 void orc_sample_texture(const pt_texture *tex, float u, float v, float rgba[4]);
 

@@ -189,7 +189,7 @@ def core_lib():
     L.pt_clear_image.argtypes = [C.c_void_p]
     L.pt_synchronize.argtypes = [C.c_void_p]
     L.pt_rng_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
-    L.pt_primary_hits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.pt_primary_hits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.pt_count_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CoreCounters)]
     L.pt_last_kernel_ms.argtypes = [C.c_void_p]
     L.pt_last_kernel_ms.restype = C.c_float

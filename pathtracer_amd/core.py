@@ -109,11 +109,16 @@ class Renderer:
         _check(self._lib.pt_rng_stream(self._ctx, seed & 0xFFFFFFFFFFFFFFFF, subsequence, out.ctypes.data, n))
         return out
 
-    def primary_hits(self, seed, jitter=True):
+    def primary_hits(self, seed, jitter=True, tree=0, with_ties=False):
+        """Face id and distance of every pixel's first camera ray, by the product walker on `tree`
+        (2 binary, 4 four-wide, 0 the render launches' choice). with_ties: also the number of rays that were
+        walked again sequentially because two candidates lay within rounding of each other."""
         ids = np.zeros((self.height, self.width), np.int32)
         dist = np.zeros((self.height, self.width), np.float32)
-        _check(self._lib.pt_primary_hits(self._ctx, int(seed), 1 if jitter else 0, ids.ctypes.data, dist.ctypes.data))
-        return ids, dist
+        redone = C.c_uint64(0)
+        _check(self._lib.pt_primary_hits(self._ctx, int(seed), 1 if jitter else 0, int(tree), ids.ctypes.data, dist.ctypes.data,
+                                         C.byref(redone)))
+        return (ids, dist, int(redone.value)) if with_ties else (ids, dist)
 
     def count_batch(self, seed, current_samples):
         c = _ffi.CoreCounters()

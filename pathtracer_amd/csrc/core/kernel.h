@@ -372,92 +372,6 @@ PT_DEV float slab_planes(float ax, float ay, float az, float bx, float by, float
 
 constexpr uint32_t kDone = 0x7FFFFFFFu; // not a node index (< 2^28 triangles => < 2^28 nodes)
 
-// bvh_intersect_iterative + the triangle half of intersect_face
-// (src/bvh.cu:239-286, src/intersect.cu:12-81, :100). Same visiting order per ray, same strict
-// "closer" test, so exact distance ties resolve to the same face. Shaped as a while-while
-// loop: every lane descends through inner nodes until it holds a leaf (or is done), then the
-// wave tests leaf triangles together, so node steps and triangle tests do not serialise
-// inside one wave iteration.
-template <bool COUNT, int STACK>
-PT_DEV HitLite trace(const KernelParams &P, f3 o, f3 d, float t_init, float t_stop, uint32_t *stack /* &lds[0][tid] */,
-                     Tally &n) {
-    HitLite h;
-    h.t = t_init;
-    h.t2 = kNoHit;
-    h.u = h.v = 0.f;
-    h.face = -1;
-    h.early = false;
-    f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const float inf = __builtin_inff();
-    const bool exact = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
-    if (COUNT) n.walks++;
-    int sp = 0;
-    uint32_t ref = P.root;
-    while (ref != kDone) {
-        while (ref < kDone) { // an inner node
-            const float4 *np = (const float4 *)(P.nodes + ref);
-            float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            if (COUNT) n.inner++;
-            region_tick<COUNT>(n, kRegInner);
-            float t1, t2;
-            if (!exact) {
-                t1 = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, h.t);
-                t2 = slab_fast(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, h.t);
-            } else {
-                t1 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, h.t);
-                t2 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, h.t);
-            }
-            uint32_t c1 = __float_as_uint(q3.x), c2 = __float_as_uint(q3.y);
-            if (t2 < t1) {
-                uint32_t tc = c1; c1 = c2; c2 = tc;
-                float tt = t1; t1 = t2; t2 = tt;
-            }
-            if (t1 == kNoHit) {
-                ref = kDone;
-                if (sp > 0) ref = stack[(--sp) * kBlock];
-            } else {
-                ref = c1;
-                if (t2 != kNoHit) {
-                    if (sp < STACK) stack[sp * kBlock] = c2; // height is checked at upload; never overflows
-                    sp++;
-                }
-            }
-        }
-        if (ref != kDone) { // a leaf
-            region_tick<COUNT>(n, kRegLeaf);
-            uint32_t first = ref & 0x0FFFFFFFu;
-            uint32_t count = ((ref >> 28) & 7u) + 1;
-            for (uint32_t k = 0; k < count; k++) {
-                const float4 *tp = (const float4 *)(P.tris + first + k);
-                float4 a = tp[0], b = tp[1], c = tp[2];
-                f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
-                if (COUNT) n.tris++;
-                f3 pvec = cross(d, e2);
-                float det = dot(e1, pvec);
-                if (det > -PT_EPS_UP && det < PT_EPS_UP) continue;
-                float inv_det = 1.0f / det;
-                f3 tvec = o - v0;
-                float u = dot(tvec, pvec) * inv_det;
-                if (u <= -PT_EPS_UP || u > 1.0f) continue;
-                f3 qvec = cross(tvec, e1);
-                float v = dot(d, qvec) * inv_det;
-                if (v <= -PT_EPS_UP || (u + v) > 1.0f) continue;
-                float t = dot(e2, qvec) * inv_det;
-                if (t >= 0 && t < h.t) {
-                    h.t = t;
-                    h.u = u;
-                    h.v = v;
-                    h.face = (int32_t)__float_as_uint(c.y);
-                    if (t <= t_stop) h.early = true;
-                }
-            }
-            ref = kDone;
-            if (sp > 0 && !h.early) ref = stack[(--sp) * kBlock];
-        }
-    }
-    return h;
-}
-
 // ---- sliced, speculative walk ------------------------------------------------------------
 //
 // The same closest-hit walk, restructured for a 64-wide wave:
@@ -1566,17 +1480,20 @@ __global__ void __launch_bounds__(kBlock, PT_MIN_WAVES) cost_probe_kernel(Kernel
     render_body<false, STACK, ROWS, WIDE>(P, nullptr, nullptr);
 }
 
-// First camera ray of every pixel: face id + distance (parity probe).
-template <int STACK>
-__global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, int32_t *__restrict__ faces, float *__restrict__ dist) {
+// First camera ray of every pixel: face id + distance (parity probe), walked by the PRODUCT walker: walk_begin /
+// walk_slice on the tree render launches use (WIDE or not), with the same start-over rule as render_body (a
+// speculative walk whose winner has another candidate within kNearHi of it is repeated sequentially on the binary
+// tree). redone counts those repeats: the "stated count of epsilon edge ties" of this launch.
+template <int STACK, bool WIDE>
+__global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, int32_t *__restrict__ faces, float *__restrict__ dist,
+                                                              unsigned long long *__restrict__ redone) {
     __shared__ uint32_t lds_stack[STACK * kBlock];
     uint32_t *stack = lds_stack + threadIdx.x;
     int px, py;
     pixel_of_thread(P, &px, &py);
-    bool inside = px < P.width && py < P.height;
+    const bool inside = px < P.width && py < P.height;
     Rng rng;
     rng_init(rng, P.jump, P.seed_lo, P.seed_hi, inside ? (uint32_t)(py * P.width + px) : 0u);
-    if (!inside) return;
     float nx, ny;
     rng_normal_pair(rng, &nx, &ny);
     if (!P.jitter) nx = ny = 0;
@@ -1586,10 +1503,31 @@ __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, in
     f3 o, d;
     camera_ray(P, u, v, &o, &d);
     Tally n = {};
-    HitLite h = trace<false, STACK>(P, o, d, kNoHit, -1.0f, stack, n);
-    size_t at = (size_t)py * (size_t)P.width + (size_t)px;
-    faces[at] = h.face;
-    if (dist) dist[at] = h.t;
+    Walk wk = {};
+    float t_init = kNoHit;
+    walk_begin<WIDE>(P, d, t_init, wk);
+    if (!inside) { // lanes outside the image take part in the wave's ballots with a finished walk
+        wk.ref = kDone;
+        wk.pleaf = 0;
+    }
+    uint32_t again = 0;
+    for (;;) {
+        walk_slice<false, STACK, WIDE>(P, o, d, t_init, -1.0f, stack, wk, n);
+        bool finished = wk.ref == kDone && wk.pleaf == 0;
+        if (finished && inside && t_init > 0.0f && wk.h.face >= 0 && wk.h.t2 <= wk.h.t * kNearHi) {
+            t_init = -t_init;
+            walk_reset(P.root, -t_init, wk);
+            finished = false;
+            again++;
+        }
+        if (__builtin_amdgcn_ballot_w64(!finished) == 0) break;
+    }
+    if (inside) {
+        size_t at = (size_t)py * (size_t)P.width + (size_t)px;
+        faces[at] = wk.h.face;
+        if (dist) dist[at] = wk.h.face >= 0 ? wk.h.t : kNoHit;
+        if (redone && again) atomicAdd(redone, (unsigned long long)again);
+    }
 }
 
 __global__ void rng_stream_kernel(const uint32_t *jump, uint32_t seed_lo, uint32_t seed_hi, uint32_t subsequence,

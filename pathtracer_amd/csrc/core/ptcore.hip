@@ -900,9 +900,23 @@ extern "C" int pt_rng_stream(pt_context *ctx, uint64_t seed, uint64_t subsequenc
     return 0;
 }
 
-extern "C" int pt_primary_hits(pt_context *ctx, int seed, int jitter, int32_t *host_face_ids, float *host_distances) {
+namespace {
+template <bool WIDE> void launch_primary(pt_context *ctx, int32_t *d_faces, float *d_dist, unsigned long long *d_redone) {
+    const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
+    dim3 grid = grid_of(ctx), block(kBlock);
+    if (need <= 32) hipLaunchKernelGGL((primary_hits_kernel<32, WIDE>), grid, block, 0, ctx->stream, ctx->P, d_faces, d_dist, d_redone);
+    else if (need <= 48) hipLaunchKernelGGL((primary_hits_kernel<48, WIDE>), grid, block, 0, ctx->stream, ctx->P, d_faces, d_dist, d_redone);
+    else hipLaunchKernelGGL((primary_hits_kernel<64, WIDE>), grid, block, 0, ctx->stream, ctx->P, d_faces, d_dist, d_redone);
+}
+} // namespace
+
+extern "C" int pt_primary_hits(pt_context *ctx, int seed, int jitter, int tree, int32_t *host_face_ids, float *host_distances,
+                               uint64_t *redone_walks) {
     if (ready(ctx)) return 1;
     if (!host_face_ids) return fail("pt_primary_hits: null buffer");
+    if (tree != 0 && tree != 2 && tree != 4) return fail("pt_primary_hits: tree must be 0, 2 or 4");
+    if (tree == 0) tree = ctx->walk_tree ? ctx->walk_tree : 2;
+    if (tree == 4 && ctx->stack_need4 > 64) return fail("pt_primary_hits: the four-wide form of this tree needs more than 64 stack entries");
     size_t n = (size_t)ctx->P.width * (size_t)ctx->P.height;
     int32_t *d_faces = nullptr;
     float *d_dist = nullptr;
@@ -913,16 +927,20 @@ extern "C" int pt_primary_hits(pt_context *ctx, int seed, int jitter, int32_t *h
         return fail("HIP error: %s (pt_primary_hits)", hipGetErrorString(e));
     }
     set_launch(ctx->P, seed, 0, 1, jitter);
-    if (ctx->bvh_height <= 33)
-        hipLaunchKernelGGL((primary_hits_kernel<32>), grid_of(ctx), dim3(kBlock), 0, ctx->stream, ctx->P, d_faces, d_dist);
-    else
-        hipLaunchKernelGGL((primary_hits_kernel<64>), grid_of(ctx), dim3(kBlock), 0, ctx->stream, ctx->P, d_faces, d_dist);
-    e = hipStreamSynchronize(ctx->stream);
+    e = hipMemsetAsync(ctx->counters.ptr, 0, sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) {
+        if (tree == 4) launch_primary<true>(ctx, d_faces, d_dist, ctx->counters.ptr);
+        else launch_primary<false>(ctx, d_faces, d_dist, ctx->counters.ptr);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    unsigned long long redone = 0;
     if (e == hipSuccess) e = hipMemcpy(host_face_ids, d_faces, n * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess && host_distances) e = hipMemcpy(host_distances, d_dist, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&redone, ctx->counters.ptr, sizeof(redone), hipMemcpyDeviceToHost);
     (void)hipFree(d_faces);
     (void)hipFree(d_dist);
     if (e != hipSuccess) return fail("HIP error: %s (pt_primary_hits)", hipGetErrorString(e));
+    if (redone_walks) *redone_walks = redone;
     return 0;
 }
 

@@ -3,6 +3,13 @@
   cornell_scene.npz   the reference's cornell.gltf after OUR host pipeline (transformed vertices
                       with tangents, faces, materials, camera) — derived arrays, not the asset —
                       so BASELINE config 1 can be rendered on the GPU box, which has no reference.
+  dragon_scene.npz, glass_mirror_scene.npz
+                      the same for dragon.gltf (BASELINE config 3) and glass_mirror.gltf (config 4, with its
+                      point light); dragon is 69 747 vertices / 139 482 faces, 10.9 MB of records before
+                      compression (the vertex and face records are stored as they cross the C ABI).
+  rose_garden_env.npz config 4's environment map: sunny_rose_garden_1k.hdr decoded by OUR .hdr reader
+                      (bit-equal to the reference's stb_image, tests/test_reference_pins.py) and point-sampled
+                      down to 256x128 RGB float texels (every 4th texel of every 4th row; alpha is 1).
   oracle_c1.json      digests of what the ORACLE produces for config 1 (256x256, 16 spp, seed 42):
                       sha256 of the linear image, of the tonemapped RGB8 buffer, of the jittered
                       primary hit ids, plus integer counters. These pin the oracle against
@@ -33,14 +40,25 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def main():
-    sc = host.Scene.load_gltf(f"{ASSETS}/cornell.gltf")
+def save_scene(name):
+    sc = host.Scene.load_gltf(f"{ASSETS}/{name}.gltf")
     cam = sc.camera
     camera = np.array(list(cam["position"]) + list(cam["target"]) + list(cam["updir"]) + [cam["yfov"]], np.float32)
-    np.savez_compressed(os.path.join(HERE, "cornell_scene.npz"),
+    np.savez_compressed(os.path.join(HERE, f"{name}_scene.npz"),
                         vertices=np.frombuffer(sc.vertices.tobytes(), np.uint8),
                         faces=np.frombuffer(sc.faces.tobytes(), np.uint8),
-                        materials=np.frombuffer(sc.materials.tobytes(), np.uint8), camera=camera)
+                        materials=np.frombuffer(sc.materials.tobytes(), np.uint8),
+                        lights=np.frombuffer(sc.lights.tobytes(), np.uint8), camera=camera)
+    return sc
+
+
+def main():
+    sc = save_scene("cornell")
+    save_scene("dragon")
+    save_scene("glass_mirror")
+    env = host.load_hdr(f"{ASSETS}/sunny_rose_garden_1k.hdr")
+    assert env.shape == (512, 1024, 4) and (env[..., 3] == 1.0).all()
+    np.savez_compressed(os.path.join(HERE, "rose_garden_env.npz"), rgb=np.ascontiguousarray(env[::4, ::4, :3]))
     bvh, lst = host.BVH(sc), host.LST(sc)
     o = ob.Oracle(sc, bvh, lst, 256, 256)
     img, ctr = o.render_batch(42, 0, 16)

@@ -1,0 +1,107 @@
+"""GPU parity at the sizes BASELINE.json names, under the gate.
+
+Every case renders on the CPU oracle (16 threads) and on the GPU with EACH form of the tree, and compares
+the linear radiance image bit for bit (a pixel that is NaN on both sides - GGX at roughness 0
+with the half vector on the normal, reference arithmetic, DESIGN.md section 5 - is the same pixel).
+
+  C2  many_lights STAND-IN (the reference's .bin does not ship) 1024x1024, one batch of 50 spp
+  C3  the reference's dragon.gltf (golden arrays)               1024x1024, one batch of 64 spp
+  C4  the reference's glass_mirror.gltf + rose-garden env       1024x1024, one batch of 50 spp
+  C5  synthetic 10 M-triangle grid                              4096x4096, 4 spp (one GPU's share of a batch)
+  soak: 20 random (scene, size, seed, split, tree, tile shape) cases with a fixed generator seed
+Oracle time on the GPU box's 16 threads: about 6 + 5 + 4 + 25 s.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from pathtracer_amd import core, scenes
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+THREADS = 16
+
+
+def _both_trees(b, w, h, seed, spp, every, clear=(0.0, 0.0, 0.0), monkeypatch=None, label=""):
+    cpu = ob.Oracle(b.scene, b.bvh, b.lst, w, h, 0.0, clear).render(seed, spp, every, threads=THREADS)
+    nonfinite = int((~np.isfinite(cpu)).sum())
+    for tree in ("wide", "binary"):
+        monkeypatch.setenv("PT_TREE", tree)
+        r = core.Renderer(0)
+        try:
+            r.upload(b.scene, b.bvh, b.lst)
+            r.configure(w, h, 0.0, clear)
+            gpu = r.render(seed, spp, every)
+            ms = r.last_kernel_ms()
+            ties = r.count_batch(seed, min(every, 4))["redone_walks"]
+        finally:
+            r.close()
+        n = util.count_different(gpu, cpu)
+        print(f"{label} {w}x{h}x{spp}spp {tree} tree: {n} of {gpu.size} floats differ; non-finite {nonfinite}; "
+              f"{ms:.1f} ms/launch; walks repeated sequentially in a {min(every, 4)}-spp launch: {ties}")
+        assert n == 0, (label, tree, n)
+    assert np.isfinite(cpu).mean() > 0.9999 and float(np.nanmean(cpu)) > 0
+    return cpu
+
+
+def test_c2_many_lights_standin_full_size(scene_dir, monkeypatch):
+    b = util.load_bundle(scenes.write_many_lights_standin(scene_dir, name="ml_c2"))
+    assert len(b.scene.faces) == 322804
+    _both_trees(b, 1024, 1024, 42, 50, 50, monkeypatch=monkeypatch, label="C2 many_lights stand-in")
+
+
+def test_c3_dragon_full_size(monkeypatch):
+    b = util.golden_scene("dragon")
+    _both_trees(b, 1024, 1024, 42, 64, 64, monkeypatch=monkeypatch, label="C3 dragon.gltf")
+
+
+def test_c4_glass_mirror_env_full_size(monkeypatch):
+    b = util.golden_scene("glass_mirror", env=True)
+    _both_trees(b, 1024, 1024, 42, 50, 50, clear=(1.0, 1.0, 1.0), monkeypatch=monkeypatch, label="C4 glass_mirror.gltf + env")
+
+
+def test_c5_grid_10m_triangles_4096(scene_dir, monkeypatch):
+    b = util.load_bundle(scenes.write_synthetic_grid(scene_dir, name="grid_c5", side=2236))
+    assert len(b.scene.faces) > 9_990_000
+    _both_trees(b, 4096, 4096, 42, 4, 4, monkeypatch=monkeypatch, label="C5 10M-triangle grid")
+    for f in os.listdir(scene_dir):  # 360 MB of generated mesh: not needed by later tests
+        if f.startswith("grid_c5"):
+            os.remove(os.path.join(scene_dir, f))
+
+
+def test_soak_slice(scene_dir, monkeypatch):
+    """tests/soak_gpu.py's generator with a fixed seed: 20 cases."""
+    rng = np.random.RandomState(20261111)
+    hdr = scenes.write_sky_hdr(scene_dir + "/soak_sky.hdr")
+    d = scene_dir
+    makers = [
+        lambda k: (scenes.write_cornell_like(d, name=f"sc{k}", detail=int(rng.randint(3, 14))), {}),
+        lambda k: (scenes.write_many_lights_standin(d, name=f"sm{k}", rings=int(rng.randint(8, 90)), segments=int(rng.randint(8, 120))), {}),
+        lambda k: (scenes.write_dragon_standin(d, name=f"sd{k}", rings=int(rng.randint(6, 70)), segments=int(rng.randint(6, 70))), {}),
+        lambda k: (scenes.write_glass_mirror_standin(d, name=f"sg{k}", detail=int(rng.randint(4, 30))), {"clear_texture": hdr}),
+        lambda k: (scenes.write_textured_standin(d, name=f"st{k}", detail=int(rng.randint(4, 24))), {}),
+    ]
+    bad = []
+    for k in range(20):
+        path, kw = makers[rng.randint(len(makers))](k)
+        b = util.load_bundle(path, **kw)
+        w, h = int(rng.randint(9, 200)), int(rng.randint(9, 160))
+        spp, every = int(rng.randint(1, 24)), int(rng.randint(1, 12))
+        seed, exposure = int(rng.randint(-5, 10 ** 6)), float(rng.choice([0.0, 0.5, -1.0, 2.0]))
+        clear = tuple(float(x) for x in rng.choice([0.0, 0.3, 1.0], 3))
+        monkeypatch.setenv("PT_TREE", str(rng.choice(["wide", "binary"])))
+        monkeypatch.setenv("PT_TILE_ROWS", str(rng.choice(["8", "16"])))
+        r = core.Renderer(0)
+        try:
+            r.upload(b.scene, b.bvh, b.lst)
+            r.configure(w, h, exposure, clear)
+            gpu = r.render(seed, spp, every)
+        finally:
+            r.close()
+        cpu = ob.Oracle(b.scene, b.bvh, b.lst, w, h, exposure, clear).render(seed, spp, every, threads=THREADS)
+        if util.count_different(gpu, cpu):
+            bad.append((k, os.path.basename(path), w, h, spp, every, seed))
+    assert not bad, bad

@@ -508,3 +508,41 @@ def test_texture_sampler_modes():
     L.orc_sample_texture(C.byref(t), 0.3, 0.6, a.ctypes.data)
     L.orc_sample_texture(C.byref(t), 1.7, 1.4, b.ctypes.data)
     assert np.allclose(a, b, atol=1e-6)
+
+
+# ---- golden fixtures of the reference's own scenes (available on the GPU box too) --------------------
+
+@pytest.mark.parametrize("name,verts,faces,nodes,height,lst", [
+    ("cornell", 2549, 1940, 2215, 16, 2), ("glass_mirror", 1142, 1932, 2027, 14, 3), ("dragon", 69747, 139482, 168503, 25, 2)])
+def test_golden_scene_fixtures_rebuild_the_surveyed_trees(name, verts, faces, nodes, height, lst):
+    """tests/golden/<name>_scene.npz through OUR builder gives the node count and height SURVEY.md §3.3
+    recorded from the REFERENCE's builder on the same asset (and §8's LST sizes)."""
+    b = util.golden_scene(name)
+    assert (len(b.scene.vertices), len(b.scene.faces)) == (verts, faces)
+    assert (b.bvh.stats["node_count"], b.bvh.stats["max_depth"], len(b.lst.nodes)) == (nodes, height, lst)
+    stats = json.load(open(os.path.join(util.GOLDEN, "scene_stats.json")))[name]["ours"]
+    assert hashlib.sha256(np.ascontiguousarray(b.bvh.nodes).tobytes()).hexdigest() == stats["nodes_sha256"]
+    assert hashlib.sha256(np.ascontiguousarray(b.scene.vertices).tobytes()).hexdigest() == stats["vertices_sha256"]
+
+
+def test_nonfinite_pixels_come_from_ggx_at_roughness_zero():
+    """VERDICT r1 item 7. The reference's own cornell.gltf, 256x256, ONE batch of 32 spp, seed 42: pixel (34, 151)
+    is NaN. Cause (oracle diagnostics): sample 27 reaches material SPHERE1 (roughnessFactor 0) and the half
+    vector of the light sample rounds onto the normal, h.z == 1.0f, so normal_factor_ggx (brdf.cu:11-15)
+    evaluates alpha^2 / (pi * (h.z^2 * (alpha^2 - 1) + 1)^2) = 0 / 0. Reference arithmetic, not a stand-in
+    artefact: every roughness-0 material (cornell SPHERE1, dragon GROUND and DRAGON, glass_mirror MIRROR and
+    GLASS) has zero specular except on that measure-zero set, where it is NaN; the reference's check_sanity
+    (image.cu:57-70) then refuses the image, and so does pth_tonemap_rgb8."""
+    b = util.golden_scene("cornell")
+    o = ob.Oracle(b.scene, b.bvh, b.lst, 256, 256)
+    img, _ = o.render_batch(42, 0, 32, rows=(151, 152))
+    bad = np.flatnonzero(~np.isfinite(img[151]).all(axis=1))
+    assert list(bad) == [34]
+    d = o.find_nonfinite(42, 32, 34, 151)
+    assert d is not None and d["where"] == 1 and d["sample"] == 27
+    assert b.scene.materials["name"][d["material"]] == b"SPHERE1" and d["roughness"] == 0.0
+    assert d["h_z"] == 1.0
+    assert o.find_nonfinite(42, 32, 35, 151) is None
+    # the tonemapper refuses such an image, like the reference's check_sanity
+    with pytest.raises(host.HostError):
+        host.tonemap_rgb8(img[151:152])

@@ -48,6 +48,8 @@ def lib():
                                       C.c_int, C.POINTER(_ffi.Counters)]
         L.orc_rng_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.orc_rng_stream.restype = None
+        L.orc_rng_set_scramble.argtypes = [C.c_void_p]
+        L.orc_rng_set_scramble.restype = None
         L.orc_rng_state.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
         L.orc_rng_state.restype = None
         L.orc_rng_sequence_jump_matrix.argtypes = [C.c_int, C.c_void_p]
@@ -127,6 +129,16 @@ def rng_stream(seed, subsequence, n):
     out = np.zeros(n, np.uint32)
     lib().orc_rng_stream(seed & 0xFFFFFFFFFFFFFFFF, subsequence, out.ctypes.data, n)
     return out
+
+
+def set_scramble(constants=None):
+    """Test hook: the four seed-scramble constants (None = cuRAND's, as recalled)."""
+    if constants is None:
+        lib().orc_rng_set_scramble(None)
+    else:
+        a = np.asarray(constants, np.uint32)
+        assert a.shape == (4,)
+        lib().orc_rng_set_scramble(a.ctypes.data)
 
 
 def rng_state(seed, subsequence):

@@ -133,13 +133,18 @@ struct Rng {
     float extra;
 };
 
+// The four constants of curand_init's seed scramble, as recalled from the public curand_kernel.h (UNVERIFIED:
+// cuRAND is not in this image). orc_rng_set_scramble swaps in another set for the cross-check against rocRAND's
+// engine, whose structure is the same and whose constants differ (rocrand_xorwow.h:113-116).
+uint32_t g_scramble[4] = {0xaad26b49u, 0xf7dcefddu, 1099087573u, 2591861531u};
+
 // curand_init(seed, subsequence, 0, &state) for curandStateXORWOW_t.
 void rng_init(Rng &s, uint64_t seed, uint64_t subsequence) {
     std::call_once(g_jump_once, build_jump);
-    uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u;
-    uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
-    uint32_t t0 = 1099087573u * s0;
-    uint32_t t1 = 2591861531u * s1;
+    uint32_t s0 = (uint32_t)seed ^ g_scramble[0];
+    uint32_t s1 = (uint32_t)(seed >> 32) ^ g_scramble[1];
+    uint32_t t0 = g_scramble[2] * s0;
+    uint32_t t1 = g_scramble[3] * s1;
     s.d = 6615241u + t1 + t0;
     s.v[0] = 123456789u + t0;
     s.v[1] = 362436069u ^ t0;
@@ -790,6 +795,11 @@ extern "C" int orc_find_nonfinite(const orc_inputs *in, int seed, int cur, int p
         (void)integrate_Li(c, camera_ray(in->scene->camera, u, v));
     }
     return out->found;
+}
+
+extern "C" void orc_rng_set_scramble(const uint32_t constants[4]) {
+    static const uint32_t curand[4] = {0xaad26b49u, 0xf7dcefddu, 1099087573u, 2591861531u};
+    memcpy(g_scramble, constants ? constants : curand, sizeof(g_scramble));
 }
 
 extern "C" void orc_rng_state(uint64_t seed, uint64_t subsequence, uint32_t state[6]) {

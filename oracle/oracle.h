@@ -64,6 +64,11 @@ int orc_render_rows(const orc_inputs *in, int seed, int previous_samples, int cu
 /* First n outputs of curand(&state) after curand_init(seed, subsequence, 0). */
 void orc_rng_stream(uint64_t seed, uint64_t subsequence, uint32_t *out, int n);
 
+/* TEST HOOK: replaces the four seed-scramble constants {C0, C1, M0, M1} (s0 = lo32(seed) ^ C0, s1 = hi32 ^ C1,
+ * t0 = M0 * s0, t1 = M1 * s1) for every later call, in every thread; NULL restores the cuRAND set. Used only
+ * to compare the whole generator with rocRAND's engine, whose constants differ. Not thread-safe. */
+void orc_rng_set_scramble(const uint32_t constants[4]);
+
 /* XORWOW state (v[0..4], d) right after curand_init(seed, subsequence, 0). */
 void orc_rng_state(uint64_t seed, uint64_t subsequence, uint32_t state[6]);
 

@@ -45,7 +45,7 @@ def combine(acc, local_spp, total_spp, group=None, dst=None):
     """Weighted sum of the per-rank running means. acc is modified in place and holds the final
     image on every rank (all_reduce) or on `dst` only (reduce)."""
     acc.mul_(float(local_spp) / float(total_spp))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():  # (a one-rank group still goes through the collective)
         if dst is None:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
         else:

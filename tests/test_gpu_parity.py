@@ -205,6 +205,33 @@ def test_sharded_render_single_rank(renderer, cornell_like):
     _assert_images_match(gpu.reshape(cpu.shape), cpu)
 
 
+def test_sharded_render_through_rccl_one_rank(renderer, cornell_like):
+    """the N-GPU path's collective on hardware. A one-rank "nccl" (= RCCL) process group:
+    render_sharded launches on its side stream and combine() runs the real all_reduce on the accumulator.
+    (The N > 1 arithmetic - plan, weights, sum - is covered by the gloo world-2 test on CPU.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import render
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    w, h = 72, 40
+    o = _setup(renderer, cornell_like, w, h)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        img = render.render_sharded(renderer, w, h, 9, 10, 4)
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)  # the group is live
+        torch.cuda.synchronize()
+        assert float(t.sum()) == 4.0
+        gpu = img.cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+    _assert_images_match(gpu, o.render(9, 10, 4))
+
+
 def test_material_textures_and_alpha_modes(renderer, scene_dir):
     """Base-colour + metallic-roughness textures (mirrored / repeat / clamp wrap, linear and
     nearest filter, uvs outside [0,1]), MASK cutoff and BLEND stochastic pass-through."""

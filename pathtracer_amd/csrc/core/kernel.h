@@ -405,6 +405,17 @@ constexpr uint32_t kDone = 0x7FFFFFFFu; // not a node index (< 2^28 triangles =>
 #define PT_BLOCKED_SHIFT 0 /* leave the node loop when blocked lanes >= stepping lanes >> shift */
 #endif
 
+// The lane's traversal stack of child references: every entry in LDS, [entry][lane], so a wave's push or pop is
+// one conflict-free ds_write_b32 / ds_read_b32. (walk_slice takes the stack as a type: round 2 also measured a
+// 16-entry LDS stack whose deeper entries spill to private memory, for kernels that need the LDS for path
+// records; profiles/r02_kernel_experiments.md.)
+template <int ENTRIES> struct LdsStack {
+    uint32_t *base; // &lds[lane]
+    static constexpr bool kUnchecked = true; // the upload checked the bound: slots above sp may be written freely
+    static constexpr int kFree = ENTRIES;
+    PT_DEV void put(int i, uint32_t v) { base[i * kBlock] = v; }
+    PT_DEV uint32_t get(int i) const { return base[i * kBlock]; }
+};
 struct Walk {
     uint32_t ref;   // next node/leaf reference, kDone when the walk is finished
     uint32_t pleaf; // parked leaf reference, 0 = none
@@ -538,8 +549,8 @@ PT_DEV void walk_begin(const KernelParams &P, f3 d, float &t_init, Walk &w) {
     walk_reset(ray_is_exact<WIDE>(d) ? P.root : P.root4, t_init, w);
 }
 
-template <bool COUNT, int STACK, bool WIDE>
-PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_stop, uint32_t *stack, Walk &w, Tally &n) {
+template <bool COUNT, bool WIDE, class STK>
+PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_stop, STK &stack, Walk &w, Tally &n) {
     f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float inf = __builtin_inff();
     const bool inf_rinv = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
@@ -606,15 +617,22 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
 #undef PT_CSWAP
                     if (t0 == kNoHit) {
                         next = kDone;
-                        if (w.sp > 0) next = stack[(--w.sp) * kBlock];
+                        if (w.sp > 0) next = stack.get(--w.sp);
                     } else {
                         next = c0;
-                        // hits sort before misses, so the pushed entries are a prefix of (c3, c2, c1) reversed;
-                        // slots above sp are free (the stack bound is checked at upload), write them all
+                        // hits sort before misses, so the pushed entries are a prefix of (c3, c2, c1) reversed
                         int h3 = t3 != kNoHit, h2 = t2 != kNoHit, h1 = t1 != kNoHit;
-                        stack[w.sp * kBlock] = h3 ? c3 : (h2 ? c2 : c1);
-                        stack[(w.sp + 1) * kBlock] = h3 ? c2 : c1;
-                        stack[(w.sp + 2) * kBlock] = c1;
+                        if (STK::kUnchecked || w.sp + 3 <= STK::kFree) {
+                            // slots above sp are free (the stack bound is checked at upload): write all three
+                            stack.put(w.sp, h3 ? c3 : (h2 ? c2 : c1));
+                            stack.put(w.sp + 1, h3 ? c2 : c1);
+                            stack.put(w.sp + 2, c1);
+                        } else { // a stack type that checks its bounds: only what is pushed
+                            int at = w.sp;
+                            if (h3) stack.put(at++, c3);
+                            if (h2) stack.put(at++, c2);
+                            if (h1) stack.put(at++, c1);
+                        }
                         w.sp += h3 + h2 + h1;
                     }
                 } else {
@@ -637,11 +655,11 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
                     }
                     if (t1 == kNoHit) {
                         next = kDone;
-                        if (w.sp > 0) next = stack[(--w.sp) * kBlock];
+                        if (w.sp > 0) next = stack.get(--w.sp);
                     } else {
                         next = c1;
                         if (t2 != kNoHit) {
-                            stack[w.sp * kBlock] = c2;
+                            stack.put(w.sp, c2);
                             w.sp++;
                         }
                     }
@@ -649,7 +667,7 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
                 if (next > kDone && w.pleaf == 0) { // a leaf and room to park it: keep descending
                     w.pleaf = next;
                     next = kDone;
-                    if (w.sp > 0 && !seq) next = stack[(--w.sp) * kBlock]; // (a sequential walk waits for the leaf test)
+                    if (w.sp > 0 && !seq) next = stack.get(--w.sp); // (a sequential walk waits for the leaf test)
                 }
                 w.ref = next;
             }
@@ -670,9 +688,9 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
                 } else if (w.ref > kDone) { // standing on the next leaf: park it, step off
                     w.pleaf = w.ref;
                     w.ref = kDone;
-                    if (w.sp > 0 && !seq) w.ref = stack[(--w.sp) * kBlock];
+                    if (w.sp > 0 && !seq) w.ref = stack.get(--w.sp);
                 } else if (w.ref == kDone && w.sp > 0) { // a sequential walk waited for this leaf: on it goes
-                    w.ref = stack[(--w.sp) * kBlock];
+                    w.ref = stack.get(--w.sp);
                     if (w.ref > kDone) { // to another leaf: that one is next, and again the walk waits for it
                         w.pleaf = w.ref;
                         w.ref = kDone;
@@ -1275,7 +1293,8 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
     __shared__ uint32_t lds_stack[STACK * kBlock];
     __shared__ uint32_t lds_ring[ROWS > 8 ? kRingWords * kRing : 1];
     __shared__ unsigned long long lds_time[COUNT ? 8 : 1];
-    uint32_t *stack = lds_stack + threadIdx.x;
+    LdsStack<STACK> stack;
+    stack.base = lds_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x;
 
     uint32_t tx, ty;
@@ -1397,7 +1416,7 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
             if (COUNT) n.walks++;
             walking = true;
         }
-        walk_slice<COUNT, STACK, WIDE>(P, s.ro, s.rd, s.t_init, s.t_stop, stack, wk, n);
+        walk_slice<COUNT, WIDE>(P, s.ro, s.rd, s.t_init, s.t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
         bool finished = active && wk.ref == kDone && wk.pleaf == 0;
         // A speculative walk whose winner has another candidate within rounding of it starts over as a sequential
@@ -1488,7 +1507,8 @@ template <int STACK, bool WIDE>
 __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, int32_t *__restrict__ faces, float *__restrict__ dist,
                                                               unsigned long long *__restrict__ redone) {
     __shared__ uint32_t lds_stack[STACK * kBlock];
-    uint32_t *stack = lds_stack + threadIdx.x;
+    LdsStack<STACK> stack;
+    stack.base = lds_stack + threadIdx.x;
     int px, py;
     pixel_of_thread(P, &px, &py);
     const bool inside = px < P.width && py < P.height;
@@ -1512,7 +1532,7 @@ __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, in
     }
     uint32_t again = 0;
     for (;;) {
-        walk_slice<false, STACK, WIDE>(P, o, d, t_init, -1.0f, stack, wk, n);
+        walk_slice<false, WIDE>(P, o, d, t_init, -1.0f, stack, wk, n);
         bool finished = wk.ref == kDone && wk.pleaf == 0;
         if (finished && inside && t_init > 0.0f && wk.h.face >= 0 && wk.h.t2 <= wk.h.t * kNearHi) {
             t_init = -t_init;

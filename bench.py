@@ -34,20 +34,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def algorithmic_bytes(c, width, height, tree=2):
-    """64 B per inner-node visit (two child boxes + two references; 128 B when the
-    launch walked the four-wide form of the tree, four boxes + four references), 40 B per triangle
-    test (positions + id), 240 B per shaded hit (face + 3 x (normal, tangent, uv) + material), 24 B
-    per pixel per launch (accumulator read + write)."""
-    node = 128 if tree == 4 else 64
+    """64 B per inner-node visit of the binary tree (two child boxes + two references); a visit
+    of the four-wide form loads 112 B (four boxes = 96 B + four references = 16 B: the 7 dwordx4 loads of
+    walk_slice; the record is padded to 128 B, the padding is not fetched). 40 B per triangle test (positions
+    + id), 240 B per shaded hit (face + 3 x (normal, tangent, uv) + material), 24 B per pixel per launch
+    (accumulator read + write)."""
+    node = 112 if tree == 4 else 64
     return node * c["inner_visits"] + 40 * c["tri_tests"] + 240 * c["shaded_hits"] + 24 * width * height
 
 
 def cpu_baseline(scene, bvh, lst, threads):
-    """The oracle ("port") on 128 image rows x 1024 px x 50 spp of the same workload."""
+    """The oracle ("port") on the 256 middle image rows x 1024 px x 50 spp of the same workload (a quarter of a step)."""
     from oracle import binding as ob
     import numpy as np
     o = ob.Oracle(scene, bvh, lst, WIDTH, HEIGHT)
-    rows = (HEIGHT // 2 - 64, HEIGHT // 2 + 64)
+    rows = (HEIGHT // 2 - 128, HEIGHT // 2 + 128)
     img = np.zeros((HEIGHT, WIDTH, 3), np.float32)
     t0 = time.perf_counter()
     _, ctr = o.render_batch(SEED, 0, SPP_PER_STEP, img, threads=threads, rows=rows)
@@ -58,11 +59,11 @@ def cpu_baseline(scene, bvh, lst, threads):
             "mrays_per_s": round(ctr["rays"] / dt / 1e6, 3)}
 
 
-def pmc_traffic():
-    """Fabric/HBM bytes per launch of the render kernel from the newest committed PMC summary
-    (profiles/rNN_pmc_*.json: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE on this
-    workload, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950). Counters cannot be read
-    from inside this process, so the figure is the profiled one, not a live one."""
+def pmc_profile():
+    """The newest committed PMC summary of this workload's render kernel (profiles/rNN_pmc_*.json: separate
+    rocprofv3 --pmc passes, made by tools/profile_round.sh + tools/summarize_profiles.py). Hardware counters
+    cannot be read from inside this process, so what the bench line quotes from here (fabric traffic, VALU
+    busy, lane utilisation) is the PROFILED launch of the same command, named by its file, not a live figure."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_*.json")),
@@ -71,10 +72,10 @@ def pmc_traffic():
         try:
             d = json.load(open(f)).get("derived", {})
             if "hbm_traffic_per_launch" in d:
-                return int(d["hbm_traffic_per_launch"]), os.path.join("profiles", os.path.basename(f))
+                return d, os.path.join("profiles", os.path.basename(f))
         except (OSError, ValueError):
             continue
-    return None, None
+    return {}, None
 
 
 def main():
@@ -159,29 +160,59 @@ def main():
         tree = r.walk_tree()
         abytes = algorithmic_bytes(counters, WIDTH, HEIGHT, tree)
         achieved = abytes / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic()
+        prof, prof_src = pmc_profile()
+        traffic = int(prof["hbm_traffic_per_launch"]) if "hbm_traffic_per_launch" in prof else None
+        # lane utilisation of the instrumented launch, weighted by the time the waves spent in each region
+        lu, ts = counters.get("lane_utilisation", {}), counters.get("time_share", {})
+        live_lanes = None
+        if ts and lu:
+            parts = [("node_phases", "inner"), ("leaf_phases", "leaf"), ("vertex_handler", "main"), ("shadow_results", "nee")]
+            w = sum(ts[a] for a, _ in parts)
+            live_lanes = round(sum(ts[a] * (lu[b] or 0.0) for a, b in parts) / w, 4) if w else None
         out = {
-            "metric": "Msamples/s (node) many_lights 1024x1024x200spp", "value": round(samples / elapsed / 1e6, 3),
+            "metric": f"Msamples/s (node) many_lights STAND-IN 1024x1024, {spp_total} spp in steps of {SPP_PER_STEP}",
+            "value": round(samples / elapsed / 1e6, 3),
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "many_lights STAND-IN (room+point+sun+emitter, 322804 tris) 1024x1024, "
                                    f"{SPP_PER_STEP} spp per step, seed 42+batch", "resolution": [WIDTH, HEIGHT],
                        "spp_per_step": SPP_PER_STEP, "spp_total": spp_total, "parallelism": f"sample-shard x{world}",
-                       "walk_tree": tree, "bvh_nodes": int(bvh.node_count), "faces": int(len(scene.faces)), "lst_nodes": int(len(lst.nodes))},
+                       "walk_tree": tree, "bvh_nodes": int(bvh.node_count), "faces": int(len(scene.faces)), "lst_nodes": int(len(lst.nodes)),
+                       "parity": "bit-identical to the CPU oracle (tests/test_gpu_full_size.py); oracle vs cuRAND: XORWOW "
+                                 "scramble constants and Box-Muller float path unverified (cuRAND absent from the image)"},
             "kernel_ms_per_step": round(avg_ms, 3),
             "kernel_msamples_per_s": round(WIDTH * HEIGHT * SPP_PER_STEP / (avg_ms * 1e-3) / 1e6, 3),
             "mrays_per_s": round(counters["rays"] / (avg_ms * 1e-3) / 1e6 * world, 2),
             "mtraversals_per_s": round(counters["traversals"] / (avg_ms * 1e-3) / 1e6 * world, 2),
             "counters_per_step": counters,
             "image_finite": finite, "image_mean": round(mean, 6),
+            # Contract form: algorithmic bytes / launch time against the HBM peak. The bytes are served by
+            # L2 / Infinity Cache (fabric traffic is a tenth of them), so this fraction does not bind; the VALU
+            # object below says what does.
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "render_kernel<COUNT=false, STACK, ROWS=8, WIDE=%s>" % ("true" if tree == 4 else "false"), "algorithmic_bytes_per_launch": int(abytes)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": prof_src,
+                         "traffic_over_algorithmic": round(traffic / abytes, 4) if traffic else None,
+                         "kernel": "render_kernel<COUNT=false, STACK, ROWS=8, WIDE=%s>" % ("true" if tree == 4 else "false"),
+                         "algorithmic_bytes_per_launch": int(abytes),
+                         "bytes_per_unit": {"inner_visit": 112 if tree == 4 else 64, "triangle_test": 40, "shaded_hit": 240, "pixel": 24}},
+            # What binds: VALU issue under divergence. busy = wave-level VALU instructions x 4 cycles / (1024 SIMDs x
+            # launch cycles); lanes = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); both from the profiled launch.
+            "roofline_valu": {"bound": "valu", "busy": round(prof["valu_busy"], 4) if "valu_busy" in prof else None,
+                              "lane_utilisation": round(prof["valu_lane_utilisation"], 4) if "valu_lane_utilisation" in prof else None,
+                              "useful_issue_frac": round(prof["valu_useful_issue"], 4) if "valu_useful_issue" in prof else None,
+                              "wave_instructions_per_launch": int(prof["valu_wave_instructions"]) if "valu_wave_instructions" in prof else None,
+                              "peak": "1024 SIMDs x 1 wave64 VALU instruction / 4 cycles", "source": prof_src,
+                              "live_lane_utilisation_instrumented": live_lanes},
         }
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
-            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+            # every core this process may use: its affinity mask, and the share the GPU box assigns to one GPU's job
+            # (it exports OMP_NUM_THREADS = 16 and kills jobs that oversubscribe; os.cpu_count() there is the whole
+            # 8-GPU machine)
+            allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            threads = max(1, min(allowed, int(os.environ.get("OMP_NUM_THREADS", str(allowed)))))
             out["cpu_baseline"] = cpu_baseline(scene, bvh, lst, threads)
+            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         print(json.dumps(out), flush=True)
 
     r.close()

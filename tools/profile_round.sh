@@ -10,7 +10,7 @@ tag=${1:?tag}
 R=$(pwd)
 out=$R/gpurun_out/$tag
 mkdir -p "$out"
-timeout -k 10 300 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
+timeout -k 10 400 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 170 rocprofv3 --kernel-trace --stats -d "$out/stats" -o vm -- python3 "$R/bench.py" --no-cpu-baseline > "$out/stats.log" 2>&1
 pass() { # name counters...

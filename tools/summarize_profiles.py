@@ -57,6 +57,14 @@ def pmc(root, out, algorithmic=None):
             der["algorithmic_bytes_per_launch"] = int(algorithmic)
     if "p2" in P and "SQ_THREAD_CYCLES_VALU" in P["p2"]:
         der["valu_lane_utilisation"] = P["p2"]["SQ_THREAD_CYCLES_VALU"] / (64 * P["p2"]["SQ_ACTIVE_INST_VALU"])
+    if "p2" in P and "p4" in P and "GRBM_GUI_ACTIVE" in P["p4"]:
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles; 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD 4 cycles
+        cycles = P["p4"]["GRBM_GUI_ACTIVE"] / 8.0
+        der["launch_cycles_per_xcd"] = cycles
+        der["valu_busy"] = P["p2"]["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles)
+        if "valu_lane_utilisation" in der:
+            der["valu_useful_issue"] = der["valu_busy"] * der["valu_lane_utilisation"]
+        der["valu_wave_instructions"] = P["p2"]["SQ_ACTIVE_INST_VALU"]
     if "p3" in P and "TCC_REQ_sum" in P["p3"]:
         der["l2_hit_rate"] = P["p3"]["TCC_HIT_sum"] / P["p3"]["TCC_REQ_sum"]
     if "p1" in P and "p2" in P and "SQ_WAVE_CYCLES" in P["p1"]:

@@ -135,6 +135,21 @@ int pt_read_image(pt_context *ctx, float *host_rgb);
 int pt_clear_image(pt_context *ctx);
 int pt_synchronize(pt_context *ctx);
 
+/* ---- multi-GPU in one process (no counterpart in the reference, which is single-GPU: SURVEY.md §8e) ----
+ * One context per listed device plus one RCCL communicator over them (librccl.so is opened on first use).
+ * Upload the scene, BVH and LST to, and configure, every pt_group_context(g, r) with the single-GPU calls
+ * above (the scene is replicated). pt_group_render is the reference's batch loop (src/main.cu:101-133)
+ * sharded by batch: batch b runs on rank b mod N with seed + b into that rank's accumulator (running mean of
+ * its own batches); then every rank scales its mean by its share of the samples and ONE ncclReduce(sum) over
+ * xGMI leaves the image on rank 0: pt_read_image(pt_group_context(g, 0), ...). Equal to the single-GPU run
+ * with the same samples_every_update up to fp32 summation order; with one device, bit for bit. Blocking. */
+typedef struct pt_group pt_group;
+int pt_group_create(const int *devices, int count, pt_group **out);
+void pt_group_destroy(pt_group *group);
+int pt_group_size(pt_group *group);
+pt_context *pt_group_context(pt_group *group, int rank);
+int pt_group_render(pt_group *group, int seed, int samples, int samples_every_update);
+
 /* ---- verification / measurement hooks (no counterpart in the reference) ---- */
 
 /* First n outputs of the device XORWOW stream for (seed, subsequence, offset 0):

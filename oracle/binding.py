@@ -56,6 +56,7 @@ def lib():
         L.orc_rng_sequence_jump_matrix.restype = None
         L.orc_primary_hits.argtypes = [C.POINTER(Inputs), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_find_nonfinite.argtypes = [C.POINTER(Inputs), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(NonfiniteDiag)]
+        L.orc_tonemap_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_sample_texture.argtypes = [C.POINTER(_ffi.Texture), C.c_float, C.c_float, C.c_void_p]
         L.orc_sample_texture.restype = None
         L.orc_logf.argtypes = [C.c_float]
@@ -123,6 +124,16 @@ class Oracle:
         if rc:
             raise RuntimeError("oracle primary_hits failed")
         return ids, dist
+
+
+def tonemap_rgb8(linear):
+    """The oracle's restatement of write_image's 8-bit buffer (src/image.cu:72-99)."""
+    linear = np.ascontiguousarray(linear, dtype=np.float32)
+    h, w = linear.shape[:2]
+    out = np.zeros((h, w, 3), np.uint8)
+    if lib().orc_tonemap_rgb8(linear.ctypes.data, w, h, out.ctypes.data):
+        raise ValueError("non-finite pixel")
+    return out
 
 
 def rng_stream(seed, subsequence, n):

@@ -852,3 +852,43 @@ extern "C" float orc_logf(float x) { return pt_logf(x); }
 extern "C" void orc_sincosf(float x, float *s, float *c) { pt_sincosf(x, s, c); }
 extern "C" float orc_atan2f(float y, float x) { return pt_atan2f(y, x); }
 extern "C" float orc_acosf(float x) { return pt_acosf(x); }
+
+// ---- write_image's 8-bit buffer (src/image.cu:11-99), restated for the PNG / CLI tests -------------------------
+// Same hidden doubles: `c <= 0.0031308`, `12.92 * c`, `1.055 * powf(c, 1 / 2.4) - 0.055`, `c < 0.0`, `c >= 1.0`.
+// A pure-black pixel makes l_out / l_in = 0 / 0 = NaN in the reference; NaN fails both clamps and (uint8_t)(255 * NaN)
+// is undefined, 0 on x86-64 (SURVEY.md section 8c "tonemap trap"): stated here as 0. Returns 1 on a non-finite input
+// (check_sanity exits there, image.cu:57-70).
+namespace {
+inline float tm_luminance(const float *v) { return v[0] * 0.2126f + (v[1] * 0.7152f + v[2] * 0.0722f); } // :20-22, Vec3::dot
+inline float tm_gamma(float c) {                                                                              // :40-47
+    if ((double)c <= 0.0031308) return (float)(12.92 * (double)c);
+    return (float)(1.055 * (double)powf(c, (float)(1 / 2.4)) - 0.055);
+}
+inline uint8_t tm_clamp_256(float c) {                                                                        // :11-17
+    if (c != c) return 0;
+    if ((double)c < 0.0) c = 0.0f;
+    if ((double)c >= 1.0) c = 1.0f;
+    return (uint8_t)(255 * c);
+}
+} // namespace
+
+extern "C" int orc_tonemap_rgb8(const float *linear, int width, int height, uint8_t *out) {
+    const float one[3] = {1, 1, 1};
+    float white = tm_luminance(one);
+    for (size_t i = 0; i < (size_t)width * (size_t)height; i++) {
+        const float *c = linear + 3 * i;
+        if (!std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) return 1;
+        white = fmaxf(white, tm_luminance(c));
+    }
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const float *c = linear + 3 * ((size_t)y * (size_t)width + (size_t)x);
+            float l_old = tm_luminance(c);                                            // reinhard_extended_luminance :29-34
+            float numerator = l_old * (1.0f + (l_old / (white * white)));
+            float l_new = numerator / (1.0f + l_old);
+            float scale = l_new / tm_luminance(c);                                    // change_luminance :24-27
+            size_t i = ((size_t)(height - 1 - y) * (size_t)width + (size_t)x) * 3;    // vertical flip :94
+            for (int k = 0; k < 3; k++) out[i + (size_t)k] = tm_clamp_256(tm_gamma(c[k] * scale));
+        }
+    return 0;
+}

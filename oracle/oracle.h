@@ -91,6 +91,11 @@ typedef struct {
 } orc_nonfinite_diag;
 int orc_find_nonfinite(const orc_inputs *in, int seed, int current_samples, int px, int py, orc_nonfinite_diag *out);
 
+/* write_image's tonemapped 8-bit RGB buffer (src/image.cu:72-99: extended Reinhard on luminance with the white
+ * point max(1, max luminance), sRGB gamma, (uint8_t)(255 * c), vertical flip), restated independently of
+ * pathtracer_amd/csrc/host/image_io.cpp; out = width * height * 3 bytes. Returns 1 on a non-finite input. */
+int orc_tonemap_rgb8(const float *linear, int width, int height, uint8_t *out);
+
 /* Software texture fetch, exposed for unit tests. */
 void orc_sample_texture(const pt_texture *tex, float u, float v, float rgba[4]);
 

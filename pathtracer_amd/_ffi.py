@@ -185,6 +185,13 @@ def core_lib():
     L.pt_render_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.pt_render_batch_into.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.pt_render_batch_static.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RenderConfig), C.c_int, C.c_int, C.c_int]
+    L.pt_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.pt_group_destroy.argtypes = [C.c_void_p]
+    L.pt_group_destroy.restype = None
+    L.pt_group_size.argtypes = [C.c_void_p]
+    L.pt_group_context.argtypes = [C.c_void_p, C.c_int]
+    L.pt_group_context.restype = C.c_void_p
+    L.pt_group_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.pt_read_image.argtypes = [C.c_void_p, C.c_void_p]
     L.pt_clear_image.argtypes = [C.c_void_p]
     L.pt_synchronize.argtypes = [C.c_void_p]

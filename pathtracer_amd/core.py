@@ -25,12 +25,16 @@ CONTEXTS_CREATED = 0  # > 0: this process has initialised the GPU (tests that sp
 class Renderer:
     """One context = one GPU. Mirrors the device half of src/main.cu:74-111."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self._lib = _ffi.core_lib()
         self._ctx = C.c_void_p()
         global CONTEXTS_CREATED
         CONTEXTS_CREATED += 1
-        _check(self._lib.pt_create(int(device), C.byref(self._ctx)))
+        self._owned = _borrowed is None
+        if _borrowed is None:
+            _check(self._lib.pt_create(int(device), C.byref(self._ctx)))
+        else:
+            self._ctx = C.c_void_p(_borrowed)  # a context that belongs to a Group
         self.device = int(device)
         self.width = self.height = 0
         self._keep = []
@@ -140,9 +144,48 @@ class Renderer:
         return int(self._lib.pt_device_footprint(self._ctx))
 
     def close(self):
-        if self._ctx:
+        if self._ctx and self._owned:
             self._lib.pt_destroy(self._ctx)
-            self._ctx = C.c_void_p()
+        self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Group:
+    """pt_group: N GPUs in one process, batches sharded by index, one RCCL sum-reduce to rank 0
+    (include/ptcore.h, "multi-GPU in one process")."""
+
+    def __init__(self, devices):
+        self._lib = _ffi.core_lib()
+        self._g = C.c_void_p()
+        global CONTEXTS_CREATED
+        CONTEXTS_CREATED += 1
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        _check(self._lib.pt_group_create(arr, len(devices), C.byref(self._g)))
+        self.ranks = [Renderer(d, _borrowed=self._lib.pt_group_context(self._g, r)) for r, d in enumerate(devices)]
+
+    def upload(self, scene, bvh, lst):
+        for r in self.ranks:
+            r.upload(scene, bvh, lst)
+
+    def configure(self, width, height, exposure=0.0, clear_color=(0.0, 0.0, 0.0)):
+        for r in self.ranks:
+            r.configure(width, height, exposure, clear_color)
+
+    def render(self, seed, samples, samples_every_update):
+        _check(self._lib.pt_group_render(self._g, int(seed), int(samples), int(samples_every_update)))
+        return self.ranks[0].read_image()
+
+    def close(self):
+        if self._g:
+            for r in self.ranks:
+                r.close()
+            self._lib.pt_group_destroy(self._g)
+            self._g = C.c_void_p()
 
     def __del__(self):
         try:

@@ -1550,6 +1550,12 @@ __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, in
     }
 }
 
+// img[i] *= scale: a rank's running mean weighted by its share of the samples, before the sum-reduce (pt_group_render)
+__global__ void __launch_bounds__(256) scale_kernel(float *__restrict__ img, size_t n, float scale) {
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) img[i] = img[i] * scale;
+}
+
 __global__ void rng_stream_kernel(const uint32_t *jump, uint32_t seed_lo, uint32_t seed_hi, uint32_t subsequence,
                                   uint32_t *out, int count) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

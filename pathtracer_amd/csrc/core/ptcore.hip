@@ -1,6 +1,8 @@
 // ptcore.hip — C ABI of include/ptcore.h over the kernels in kernel.h.
 // gfx950 only; no CUDA-compat headers, no dual paths.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: librccl.so is opened on first use (pt_group_create)
 
 #include <algorithm>
 #include <cmath>
@@ -972,6 +974,149 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
     out->traversals = h[4];
     out->shaded_hits = h[5];
     out->bounces = h[6];
+    return 0;
+}
+
+// ---- multi-GPU in one process -------------------------------------------------------------
+// Scene, BVH and LST replicated per GPU; batch b goes to rank b mod N with seed + b; every rank keeps the running
+// mean of ITS batches in its library-owned accumulator; at the end each rank scales its mean by its share of
+// the samples and ONE ncclReduce(sum) over xGMI puts the image on rank 0. No other collective.
+
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (g_rccl.lib) return 0;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail("pt_group_create: cannot open librccl.so (%s)", dlerror());
+    Rccl r;
+    r.lib = lib;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(lib, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    r.Reduce = (decltype(r.Reduce))dlsym(lib, "ncclReduce");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(lib, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.Reduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        dlclose(lib);
+        return fail("pt_group_create: librccl.so lacks a symbol");
+    }
+    g_rccl = r;
+    return 0;
+}
+
+#define RCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return fail("RCCL error: %s (%s)", g_rccl.GetErrorString(r_), #expr);      \
+    } while (0)
+} // namespace
+
+struct pt_group {
+    std::vector<pt_context *> ctx;
+    std::vector<ncclComm_t> comm;
+};
+
+extern "C" int pt_group_create(const int *devices, int count, pt_group **out) {
+    if (!out) return fail("pt_group_create: null output pointer");
+    *out = nullptr;
+    if (!devices || count <= 0 || count > 64) return fail("pt_group_create: bad device list");
+    for (int i = 0; i < count; i++)
+        for (int j = 0; j < i; j++)
+            if (devices[i] == devices[j]) return fail("pt_group_create: device %d listed twice", devices[i]);
+    if (rccl_load()) return 1;
+    pt_group *g = new pt_group();
+    for (int i = 0; i < count; i++) {
+        pt_context *c = nullptr;
+        if (pt_create(devices[i], &c)) {
+            pt_group_destroy(g);
+            return 1;
+        }
+        g->ctx.push_back(c);
+    }
+    g->comm.assign((size_t)count, nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(g->comm.data(), count, devices);
+    if (r != ncclSuccess) {
+        g->comm.clear();
+        pt_group_destroy(g);
+        return fail("RCCL error: %s (ncclCommInitAll)", g_rccl.GetErrorString(r));
+    }
+    *out = g;
+    return 0;
+}
+
+extern "C" void pt_group_destroy(pt_group *g) {
+    if (!g) return;
+    for (size_t i = 0; i < g->comm.size(); i++)
+        if (g->comm[i]) {
+            (void)hipSetDevice(g->ctx[i]->device);
+            (void)g_rccl.CommDestroy(g->comm[i]);
+        }
+    for (pt_context *c : g->ctx) pt_destroy(c);
+    delete g;
+}
+
+extern "C" int pt_group_size(pt_group *g) { return g ? (int)g->ctx.size() : 0; }
+
+extern "C" pt_context *pt_group_context(pt_group *g, int rank) {
+    return (g && rank >= 0 && (size_t)rank < g->ctx.size()) ? g->ctx[(size_t)rank] : nullptr;
+}
+
+extern "C" int pt_group_render(pt_group *g, int seed, int samples, int samples_every_update) {
+    if (!g || g->ctx.empty()) return fail("pt_group_render: null group");
+    if (samples <= 0 || samples_every_update <= 0) return fail("pt_group_render: bad sample counts (%d, %d)", samples, samples_every_update);
+    const int n = (int)g->ctx.size();
+    const KernelParams &P0 = g->ctx[0]->P;
+    for (pt_context *c : g->ctx) {
+        if (ready(c)) return 1;
+        if (c->P.width != P0.width || c->P.height != P0.height) return fail("pt_group_render: the contexts are configured for different image sizes");
+        HIP_TRY(hipMemsetAsync(c->image.ptr, 0, c->image.bytes(), c->stream));
+    }
+    // the reference's batch loop (main.cu:101-133), batch b on rank b mod n: all launches are asynchronous on
+    // their context's stream, so the GPUs render side by side
+    std::vector<int> local((size_t)n, 0);
+    int done = 0, b = 0;
+    while (done < samples) {
+        const int cur = samples_every_update < samples - done ? samples_every_update : samples - done;
+        pt_context *c = g->ctx[(size_t)(b % n)];
+        if (pt_render_batch_into(c, c->image.ptr, nullptr, seed + b, local[(size_t)(b % n)], cur)) return 1;
+        local[(size_t)(b % n)] += cur;
+        done += cur;
+        b++;
+    }
+    // weight every rank's mean by its share of the samples, then ONE sum-reduce to rank 0
+    const size_t count = g->ctx[0]->image.count;
+    for (int r = 0; r < n; r++) {
+        pt_context *c = g->ctx[(size_t)r];
+        HIP_TRY(hipSetDevice(c->device));
+        const float scale = (float)((double)local[(size_t)r] / (double)samples);
+        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->image.ptr, count, scale);
+        HIP_TRY(hipGetLastError());
+    }
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int r = 0; r < n; r++) {
+        pt_context *c = g->ctx[(size_t)r];
+        HIP_TRY(hipSetDevice(c->device));
+        RCCL_TRY(g_rccl.Reduce(c->image.ptr, c->image.ptr, count, ncclFloat, ncclSum, 0, g->comm[(size_t)r], c->stream));
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    for (pt_context *c : g->ctx) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 

@@ -85,6 +85,54 @@ int main(int argc, char *argv[]) {
     // ########## DISPATCH #############
     int device = 0;
     if (const char *env = getenv("PT_DEVICE")) device = atoi(env);
+
+    // --gpus N (not a reference flag: the reference is single-GPU): devices PT_DEVICE .. PT_DEVICE + N - 1 of this
+    // node render the batches b = rank (mod N) side by side and ONE RCCL sum-reduce combines their accumulators
+    // (pt_group_render). The picture is written once, at the end.
+    int gpus = 0;
+    for (int i = 1; i + 1 < argc; i++)
+        if (strcmp(argv[i], "--gpus") == 0) gpus = atoi(argv[i + 1]);
+    if (gpus > 0) {
+        std::vector<int> devices;
+        for (int i = 0; i < gpus; i++) devices.push_back(device + i);
+        pt_group *group = nullptr;
+        CORE_TRY(pt_group_create(devices.data(), gpus, &group));
+        pt_render_config rc;
+        rc.resolution_x = cfg.resolution_x;
+        rc.resolution_y = cfg.resolution_y;
+        rc.output_exposure = cfg.output_exposure;
+        rc.world_clear_color = cfg.world_clear_color;
+        pth_log(3, "Copying scene, bvh_t and lst_t to %d devices... \n", gpus);
+        for (int r = 0; r < gpus; r++) {
+            pt_context *c = pt_group_context(group, r);
+            CORE_TRY(pt_scene_upload(c, desc));
+            CORE_TRY(pt_bvh_upload(c, bvh.nodes, bvh.node_count, bvh.indices, bvh.index_count));
+            CORE_TRY(pt_lst_upload(c, lst, lst_count));
+            CORE_TRY(pt_configure(c, &rc));
+        }
+        pth_log(3, "Done\n");
+        pth_log(3, "Rendering %d samples in batches of %d on %d GPUs, img size (%d, %d)\n", cfg.samples, cfg.samples_every_update,
+                gpus, cfg.resolution_x, cfg.resolution_y);
+        auto start = std::chrono::system_clock::now();
+        CORE_TRY(pt_group_render(group, cfg.seed, cfg.samples, cfg.samples_every_update));
+        float render_s = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::system_clock::now() - start).count() / 1e6f;
+        CORE_TRY(pt_read_image(pt_group_context(group, 0), h_img.data()));
+        if (pth_write_image(h_img.data(), cfg.resolution_x, cfg.resolution_y, cfg.path_render)) {
+            pth_log(1, "%s\n", pth_last_error());
+            exit(EXIT_FAILURE);
+        }
+        float elapsed = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now() - start).count() / 1000.0f;
+        pth_log(3, "Rendered %d out of %d S/px in %.1fs - %.2f S/px/s - %.2f MS/s\n", cfg.samples, cfg.samples, elapsed,
+                cfg.samples / elapsed, (float)cfg.resolution_x * cfg.resolution_y * cfg.samples / (1000000.0 * elapsed));
+        pth_log(3, "Render + reduce only: %.3fs - %.2f MS/s on %d GPUs\n", render_s,
+                (double)pixels * cfg.samples / (1e6 * (render_s > 0 ? render_s : 1e-9)), gpus);
+        pt_group_destroy(group);
+        pth_free(lst);
+        pth_bvh_free(&bvh);
+        pth_scene_free(scene);
+        pth_log_close();
+        return 0;
+    }
     pt_context *ctx = nullptr;
     CORE_TRY(pt_create(device, &ctx));
     char buf[64];

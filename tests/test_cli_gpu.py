@@ -43,5 +43,14 @@ def test_cli_renders_the_oracle_image(scene_dir, tmp_path):
 
     b = util.load_bundle(gltf)
     o = ob.Oracle(b.scene, b.bvh, b.lst, w, h, 0.5, (0.0, 0.0, 0.0))
-    expect = host.tonemap_rgb8(o.render(seed, spp, every))  # rows flipped as image.cu:94 does
+    expect = ob.tonemap_rgb8(o.render(seed, spp, every))  # the ORACLE's tonemapper (rows flipped as image.cu:94 does)
     assert np.array_equal(png[..., :3], expect)
+
+    # --gpus 1: the multi-GPU path of the CLI (pt_group_render: batches sharded over the listed devices, one RCCL
+    # sum-reduce to rank 0, one PNG at the end). With one device the picture is the same, byte for byte.
+    out2 = str(tmp_path / "out_group")
+    res = subprocess.run([a if a != out else out2 for a in argv] + ["--gpus", "1"], capture_output=True, text=True, timeout=110)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    log2 = open(os.path.join(out2, "log.txt")).read()
+    assert "on 1 GPUs" in log2 and "Rendered 10 out of 10 S/px" in log2
+    assert np.array_equal(host.load_png(os.path.join(out2, "render.png")), png)

@@ -232,6 +232,26 @@ def test_sharded_render_through_rccl_one_rank(renderer, cornell_like):
     _assert_images_match(gpu, o.render(9, 10, 4))
 
 
+def test_group_render_one_device(cornell_like):
+    """pt_group_*: the single-process multi-GPU path (one context per device, batches b = rank mod N, weights,
+    ONE ncclReduce to rank 0) with the one device this box has: the image is the oracle's, bit for bit.
+    A device listed twice is refused (RCCL needs distinct devices)."""
+    w, h = 88, 48
+    g = core.Group([0])
+    try:
+        g.upload(cornell_like.scene, cornell_like.bvh, cornell_like.lst)
+        g.configure(w, h, 0.5)
+        gpu = g.render(9, 11, 4)  # batches of 4, 4, 3
+        gpu2 = g.render(9, 11, 4)  # and again: the accumulators start from zero
+    finally:
+        g.close()
+    cpu = ob.Oracle(cornell_like.scene, cornell_like.bvh, cornell_like.lst, w, h, 0.5).render(9, 11, 4)
+    _assert_images_match(gpu, cpu)
+    _assert_images_match(gpu2, cpu)
+    with pytest.raises(core.CoreError, match="listed twice"):
+        core.Group([0, 0])
+
+
 def test_material_textures_and_alpha_modes(renderer, scene_dir):
     """Base-colour + metallic-roughness textures (mirrored / repeat / clamp wrap, linear and
     nearest filter, uvs outside [0,1]), MASK cutoff and BLEND stochastic pass-through."""

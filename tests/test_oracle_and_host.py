@@ -369,6 +369,24 @@ def test_tonemap_reference_rules():
         host.tonemap_rgb8(bad)
 
 
+def test_tonemapper_equals_the_oracle_restatement():
+    """pth_tonemap_rgb8 (threaded, image_io.cpp) against the oracle's separate restatement of image.cu:11-99,
+    byte for byte: dark and very bright images (white point below and above 1), exact zeros, a rendered
+    image. (the CLI test compared the PNG with the product's own tonemapper only.)"""
+    rng = np.random.RandomState(3)
+    imgs = [rng.rand(37, 53, 3).astype(np.float32) * s for s in (0.02, 0.9, 7.0, 300.0)]
+    z = rng.rand(16, 16, 3).astype(np.float32)
+    z[::3] = 0
+    z[1, 1] = (0, 0, 1e-30)
+    imgs.append(z)
+    b = util.golden_scene("cornell")
+    imgs.append(ob.Oracle(b.scene, b.bvh, b.lst, 96, 96).render(42, 8, 8))
+    for img in imgs:
+        assert np.array_equal(host.tonemap_rgb8(img), ob.tonemap_rgb8(img))
+    with pytest.raises(ValueError):
+        ob.tonemap_rgb8(np.full((2, 2, 3), np.nan, np.float32))
+
+
 # ---- oracle regression + flags + ABI surface ----------------------------------------------------------------
 
 def test_tonemap_threads_do_not_change_bytes(monkeypatch):

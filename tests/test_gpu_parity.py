@@ -475,6 +475,35 @@ def test_height_field_of_tiny_triangles(scene_dir, monkeypatch):
             r.close()
 
 
+def test_grazing_incidence(monkeypatch):
+    """ADVICE r1 (kernel.h margins): the distance Moeller-Trumbore computes loses relative accuracy where a ray
+    grazes a triangle (cancellation in det), so a grazing hit can land below the best distance while its box lies
+    beyond it; the speculative walks cull against other limits than the reference's loop, and nothing derives
+    that kCullSlack / kNearHi cover that. The case, built on purpose: a floor 80 units wide seen from 3e-3 above
+    it (cosine to the normal 1e-4 .. 4e-4) and lit by a point light 4e-3 above it, a sheet that crosses the
+    floor at 1e-5 rad (two candidates at almost the same distance along every ray near the crossing), fences
+    1e-5 .. 5e-4 high standing on it, an emitter 2e-3 above it. Both trees, three seeds, two launches each, and
+    the primary hits through the product walker."""
+    for scene_seed, fences in ((5, 14), (8, 40), (13, 90)):
+        b = util.grazing_scene(scene_seed, fences)
+        cpu = {}
+        for tree in ("wide", "binary"):
+            monkeypatch.setenv("PT_TREE", tree)
+            r = core.Renderer(0)
+            try:
+                o = _setup(r, b, 160, 120)
+                for seed in (3, 11, 2024):
+                    gpu = r.render(seed, 12, 6)
+                    if seed not in cpu:
+                        cpu[seed] = o.render(seed, 12, 6)
+                    _assert_images_match(gpu, cpu[seed], allow_nan=True)
+                ci, ties = _assert_primary_hits_match(r, o, 3, True)
+                assert len(np.unique(ci)) >= 6  # floor, sheet, wall, fences and the emitter are in view
+                print(f"grazing scene {scene_seed}, {tree} tree: images and primary hits identical; epsilon ties walked again {ties}")
+            finally:
+                r.close()
+
+
 def test_two_pixels_per_lane_tiles(cornell_like, monkeypatch):
     """Large images use 8x16 tiles whose 128 pixels are swapped between the 64 lanes every few
     samples (PT_TILE_ROWS=16 forces that kernel at a small size): ragged right and top edges, more

@@ -13,14 +13,19 @@
  * PARITY UNPINNED for the first-party kernel logic: the reference ships no
  * tests, golden vectors or fixtures for this path, and its
  * sources cannot be built here (they need the CUDA runtime and cuRAND headers,
- * which this image lacks; no stand-ins were written). What IS pinned:
+ * which this image lacks; no stand-ins were written). What IS pinned
+ * (DESIGN.md §5 has the table):
+ *   - the glTF loader, the .hdr/.png decoders and the tangents against the
+ *     reference's OWN vendored tinygltf, stb_image and MikkTSpace, built from
+ *     where they lie into oracle/_ref (tests/test_reference_pins.py,
+ *     tests/test_oracle_and_host.py::test_tangents_match_mikktspace_*);
  *   - scene/BVH structure counts against the figures SURVEY.md §3.3 recorded
- *     from the reference's builder (tests/test_host_pipeline.py);
- *   - tangents against the vendored MikkTSpace C library built from its own
- *     source into oracle/_ref (tests/test_tangents.py);
- *   - the XORWOW step and 2^67 jump matrices against rocRAND's published tables
- *     (tests/test_rng.py). cuRAND's seed-scramble constants are from the public
- *     curand_kernel.h as recalled in SURVEY.md §8c — unverified here.
+ *     from the reference's builder (test_scene_and_bvh_counts_match_survey,
+ *     test_golden_scene_fixtures_rebuild_the_surveyed_trees);
+ *   - the XORWOW generator end to end against rocRAND's own engine with its
+ *     constants substituted (test_whole_xorwow_engine_equals_rocrand_with_its_constants).
+ *     cuRAND's four seed-scramble constants are from the public curand_kernel.h
+ *     as recalled in SURVEY.md §8c: unverified here.
  */
 #ifndef ORACLE_H_
 #define ORACLE_H_

@@ -81,7 +81,10 @@ void node_bounds(const BuildInput &in, const uint32_t *indices, pt_bvh_node &n) 
     n.bmax = b.hi;
 }
 
-// bvh.cu:72-134. Returns best axis (-1 if every axis is degenerate).
+// bvh.cu:72-134. Returns best axis, or -1 if every axis is degenerate (all centroids of the range equal): the
+// reference asserts there (bvh.cu:131) and aborts; this builder goes on to the reference's own fallback for a failed
+// split, the median index (bvh.cu:162-167), so that scenes with coincident faces build. Every tree the reference
+// can build comes out identical.
 int best_split(const BuildInput &in, const uint32_t *indices, uint32_t start, uint32_t end, float *split_pos) {
     Box cb;
     for (uint32_t i = start; i < end; i++) cb.grow(in.centroids[indices[i]]);

@@ -23,7 +23,7 @@
 //
 // Quads do not exist at this boundary (faces are triangles, scene.cu:560-567),
 // so the quad split, quad orientation fix-up and quad epilogue are not needed.
-// tests/test_tangents.py checks this file against the vendored C library built
+// tests/test_oracle_and_host.py (test_tangents_match_mikktspace_*) and tests/test_reference_pins.py check this file against the vendored C library built
 // from its own source (oracle/_ref) when the reference tree is present.
 #include <algorithm>
 #include <cfloat>

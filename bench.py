@@ -99,8 +99,11 @@ def main():
             raise SystemExit("bench.py --gpus N with N > 1 must be launched by torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (it exports WORLD_SIZE): one rank per GPU over RCCL, also when N = 1
+    use_dist = world > 1 or "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # ---- inputs (host pipeline; not timed) ----------------------------------------------
@@ -120,14 +123,14 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
     # ---- warmup ----------------------------------------------------------------------------
     for i in range(args.warmup):
         r.render_batch_into(acc.data_ptr(), SEED + 1000 + i, 0, SPP_PER_STEP, stream)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(acc)
     acc.zero_()
     barrier()
@@ -144,7 +147,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # HIP events the library recorded around every launch, on the stream it was launched on
     kernel_ms = [r.kernel_ms(k) for k in range(min(args.steps, 64))]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -216,7 +219,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     r.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -162,6 +162,7 @@ struct AccessorView {
     size_t count;
     size_t stride;
     int component_type;
+    bool normalized;
     size_t available; // bytes from base to the end of the buffer
 };
 
@@ -180,6 +181,7 @@ AccessorView open_accessor(const Document &doc, int index) {
 
     AccessorView v;
     v.component_type = acc.at("componentType").int_or(0);
+    v.normalized = acc.at("normalized").kind == JsonValue::Bool && acc.at("normalized").b;
     v.count = (size_t)acc.at("count").number_or(0);
     int elem = component_size(v.component_type) * type_arity(acc.at("type").string_or(""));
     if (elem == 0) fail("accessor has an unknown type");
@@ -192,15 +194,34 @@ AccessorView open_accessor(const Document &doc, int index) {
     return v;
 }
 
-// scene.cu:257-319 — bytes are reinterpreted as float whatever componentType says.
+// scene.cu:257-319. A FLOAT accessor (every bundled asset) is read as the reference reads it: the bytes, as floats.
+// The reference reinterprets the bytes as float WHATEVER componentType says, which for the integer types glTF
+// allows on TEXCOORD_n (and, with KHR_mesh_quantization, on NORMAL / TANGENT / POSITION) reads garbage and runs
+// past the element. Widened here: integer components are converted as the glTF 2.0
+// specification prescribes (section 3.6.2.2 / 3.11: unsigned c / (2^bits - 1), signed max(c / (2^(bits-1) - 1), -1)
+// when `normalized`, the plain integer value otherwise). No reference output exists for such files.
+float component_as_float(const uint8_t *p, int component_type, bool normalized) {
+    switch (component_type) {
+    case 5120: { int8_t c; memcpy(&c, p, 1); float f = (float)c; if (!normalized) return f; f = f / 127.0f; return f < -1.0f ? -1.0f : f; }
+    case 5121: { uint8_t c = *p; return normalized ? (float)c / 255.0f : (float)c; }
+    case 5122: { int16_t c; memcpy(&c, p, 2); float f = (float)c; if (!normalized) return f; f = f / 32767.0f; return f < -1.0f ? -1.0f : f; }
+    case 5123: { uint16_t c; memcpy(&c, p, 2); return normalized ? (float)c / 65535.0f : (float)c; }
+    case 5125: { uint32_t c; memcpy(&c, p, 4); return (float)c; }
+    default: fail("accessor component type " + std::to_string(component_type) + " cannot be read as a vector");
+    }
+}
+
 void read_float_accessor(const Document &doc, int index, int arity, std::vector<pt_vec4> &out) {
     AccessorView v = open_accessor(doc, index);
     out.reserve(v.count);
+    const size_t comp = (size_t)component_size(v.component_type);
     for (size_t i = 0; i < v.count; i++) {
         float item[4] = {0, 0, 0, 0};
-        size_t want = sizeof(float) * (size_t)arity;
+        size_t want = comp * (size_t)arity;
         if (v.stride * i + want > v.available) fail("float accessor runs past its buffer");
-        memcpy(item, v.base + v.stride * i, want);
+        if (v.component_type == 5126) memcpy(item, v.base + v.stride * i, want);
+        else
+            for (int k = 0; k < arity; k++) item[k] = component_as_float(v.base + v.stride * i + comp * (size_t)k, v.component_type, v.normalized);
         out.push_back(pt_vec4{item[0], item[1], item[2], item[3]});
     }
 }
@@ -322,9 +343,30 @@ struct Builder {
         if (has_tangents && tangents.size() != vert_count) fail("TANGENT count differs from POSITION count");
         if (has_uvs && uvs.size() != vert_count) fail("TEXCOORD_0 count differs from POSITION count");
         if (indices.empty() || indices.size() % 3) fail("index count is not a positive multiple of 3");
-        // The reference asserts here (scene.cu:586): flat shading needs a face
-        // tangent it never computes.
-        if (!has_normals) fail("primitive without NORMAL: flat shading is not supported by the reference either");
+        // A primitive without NORMAL is flat shaded (glTF 2.0, section 3.7.2.1). The reference computes the face
+        // normal (scene.cu:577-580) and then asserts (:586): its flat path never got a tangent. Widened here
+        // (SURVEY.md section 8 f2): the primitive's vertices are un-shared, one per face corner, each carrying its
+        // face's normal normalize((B - A) x (C - A)) in WORLD space, as the reference computes it; from there on
+        // it is an ordinary smooth-shaded primitive whose three corner normals agree (interpolation returns the
+        // face normal, MikkTSpace supplies the tangents). No reference output exists for such files.
+        if (!has_normals) {
+            std::vector<pt_vec4> p2, t2, uv2;
+            std::vector<uint32_t> i2;
+            for (size_t i = 0; i < indices.size(); i++) {
+                uint32_t src = indices[i];
+                if (src >= vert_count) fail("index past the primitive's vertex count");
+                p2.push_back(positions[src]);
+                if (has_tangents) t2.push_back(tangents[src]);
+                if (has_uvs) uv2.push_back(uvs[src]);
+                i2.push_back((uint32_t)i);
+            }
+            positions.swap(p2);
+            tangents.swap(t2);
+            uvs.swap(uv2);
+            indices.swap(i2);
+            vert_count = positions.size();
+        }
+        const bool flat = !has_normals;
 
         pth_log(4, "Adding faces\n");
         uint32_t first_vertex = (uint32_t)scene.vertices.size();
@@ -332,7 +374,7 @@ struct Builder {
             pt_vertex v;
             pt_vec4 p = positions[i];
             v.position = dehomogenise(mul(M, pt_vec4{p.x, p.y, p.z, 1.0f}));
-            v.normal = normalized(mul_linear(M, v3(normals[i].x, normals[i].y, normals[i].z)));
+            v.normal = flat ? v3(0, 0, 0) : normalized(mul_linear(M, v3(normals[i].x, normals[i].y, normals[i].z)));
             if (has_tangents) {
                 pt_vec3 tw = normalized(mul_linear(M, v3(tangents[i].x, tangents[i].y, tangents[i].z)));
                 v.tangent = pt_vec4{tw.x, tw.y, tw.z, tangents[i].w};
@@ -354,6 +396,12 @@ struct Builder {
                 f.vertices[k] = first_vertex + indices[i + k];
             }
             f.shading = PT_BARY_SHADING;
+            if (flat) { // scene.cu:577-580, on the transformed positions
+                pt_vec3 A = scene.vertices[f.vertices[0]].position, B = scene.vertices[f.vertices[1]].position;
+                pt_vec3 C = scene.vertices[f.vertices[2]].position;
+                pt_vec3 n = normalized(cross(sub(B, A), sub(C, A)));
+                for (int k = 0; k < 3; k++) scene.vertices[f.vertices[k]].normal = n;
+            }
             scene.faces.push_back(f);
         }
 

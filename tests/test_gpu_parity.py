@@ -504,6 +504,33 @@ def test_grazing_incidence(monkeypatch):
                 r.close()
 
 
+def test_flat_shaded_primitive_and_quantised_uvs(renderer, scene_dir):
+    """The loader's widening through the kernel: a primitive without NORMAL (flat shaded:
+    un-shared vertices carrying the face normal) with normalised-u16 texture coordinates on a textured material."""
+    P, N, UV, idx = scenes.blob(7, 9, bump=0.3, seed=4)
+    w = scenes.GltfWriter()
+    tex = scenes.write_png_rgba8(scene_dir + "/flat_checker.png",
+                                 (np.indices((16, 16)).sum(0) % 2)[..., None].astype(np.uint8) * np.uint8([200, 120, 60, 255]) + np.uint8([40, 40, 40, 0]))
+    mat = w.material("CHECK", (1, 1, 1, 1), roughness=0.6, base_color_texture=w.texture("flat_checker.png"))
+    emit = w.material("EMIT", (0, 0, 0, 1), emissive=(1, 1, 1), emissive_strength=6)
+    w.doc.setdefault("extensionsUsed", []).append("KHR_materials_emissive_strength")
+    p = w.primitive(P, N, idx, mat, UV)
+    del p["attributes"]["NORMAL"]
+    q = np.round(np.clip(UV, 0, 1) * 65535).astype(np.uint16)
+    view = w._view(q.tobytes(), 34962)
+    w.doc["accessors"].append({"bufferView": view, "componentType": 5123, "count": len(q), "type": "VEC2", "normalized": True})
+    p["attributes"]["TEXCOORD_0"] = len(w.doc["accessors"]) - 1
+    w.node("Blob", mesh=w.mesh("Blob", [p]))
+    w.node("Light", mesh=w.mesh("Light", [scenes.unit_plane(w, emit)]), translation=(0, 0, 3), rotation=(1, 0, 0, 0))
+    w.node("Camera", camera=w.camera(0.7), translation=(0, 0, 5))
+    b = util.load_bundle(w.write(scene_dir, "flat_quantised"))
+    assert len(b.scene.vertices) == len(idx) + 4
+    o = _setup(renderer, b, 72, 64, clear=(0.05, 0.05, 0.08))
+    gpu = renderer.render(6, 10, 5)
+    _assert_images_match(gpu, o.render(6, 10, 5))
+    assert gpu.mean() > 0.02
+
+
 def test_two_pixels_per_lane_tiles(cornell_like, monkeypatch):
     """Large images use 8x16 tiles whose 128 pixels are swapped between the 64 lanes every few
     samples (PT_TILE_ROWS=16 forces that kernel at a small size): ragged right and top edges, more

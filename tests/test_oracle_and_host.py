@@ -600,3 +600,94 @@ def test_whole_xorwow_engine_equals_rocrand_with_its_constants():
     finally:
         ob.set_scramble(None)
     assert np.array_equal(ob.rng_stream(42, 7, 4), before)  # cuRAND's set is back
+
+
+# ---- loader widening: integer accessors, primitives without NORMAL -----------------------------
+
+def _raw_accessor(w, data, component_type, kind, count, normalized, stride=None):
+    view = w._view(data, 34962)
+    if stride:
+        w.doc["bufferViews"][view]["byteStride"] = stride
+    acc = {"bufferView": view, "componentType": component_type, "count": count, "type": kind}
+    if normalized:
+        acc["normalized"] = True
+    w.doc["accessors"].append(acc)
+    return len(w.doc["accessors"]) - 1
+
+
+def test_loader_reads_normalised_integer_accessors(scene_dir):
+    """TEXCOORD_0 as normalised u16 and as normalised u8, NORMAL as normalised i16 with a byteStride of 8
+    (KHR_mesh_quantization): converted as glTF 2.0 prescribes (c / 65535, c / 255, max(c / 32767, -1)), where
+    the reference reinterprets the bytes as floats (scene.cu:294). The float path stays what it was."""
+    P, N, UV, idx = scenes.blob(6, 8, bump=0.2, seed=3)
+    UV = np.clip(UV, 0, 1)
+    w = scenes.GltfWriter()
+    grey = w.material("GREY", (0.5, 0.5, 0.5, 1))
+    q16 = np.round(UV * 65535).astype(np.uint16)
+    q8 = np.round(UV * 255).astype(np.uint8)
+    n16 = np.zeros((len(N), 4), np.int16)
+    n16[:, :3] = np.round(N * 32767).astype(np.int16)
+    n16[0, :3] = (-32768, 0, 0)  # the one value that needs the clamp
+    prims = []
+    for uv_acc in (_raw_accessor(w, q16.tobytes(), 5123, "VEC2", len(UV), True),
+                   _raw_accessor(w, np.concatenate([q8, np.zeros_like(q8)], 1).tobytes(), 5121, "VEC2", len(UV), True, stride=4)):
+        p = w.primitive(P, N, idx, grey, UV)
+        p["attributes"]["TEXCOORD_0"] = uv_acc
+        p["attributes"]["NORMAL"] = _raw_accessor(w, n16.tobytes(), 5122, "VEC3", len(N), True, stride=8)
+        prims.append(p)
+    prims.append(w.primitive(P, N, idx, grey, UV))  # all float
+    w.node("Blob", mesh=w.mesh("Blob", prims))
+    w.node("Camera", camera=w.camera(0.7), translation=(0, 0, 5))
+    sc = host.Scene.load_gltf(w.write(scene_dir, "quantised"))
+    v = sc.vertices
+    n = len(P)
+    assert len(v) == 3 * n
+    f32 = np.float32
+    assert np.array_equal(v["texcoord0"][:n, :2], q16.astype(f32) / f32(65535))
+    assert np.array_equal(v["texcoord0"][n:2 * n, :2], q8.astype(f32) / f32(255))
+    assert np.array_equal(v["texcoord0"][2 * n:, :2], UV)
+    want = np.maximum(n16[:, :3].astype(f32) / f32(32767), f32(-1))
+    want = want / np.linalg.norm(want.astype(np.float64), axis=1, keepdims=True)
+    assert np.abs(v["normal"][:n] - want).max() < 1e-6 and np.abs(v["normal"][0] - (-1, 0, 0)).max() < 1e-7
+    assert np.abs(v["normal"][2 * n:] - N / np.linalg.norm(N, axis=1, keepdims=True)).max() < 1e-6
+
+
+def test_loader_flat_shades_a_primitive_without_normals(scene_dir):
+    """No NORMAL attribute: the reference computes the face normal and asserts (scene.cu:577-586). Here the
+    vertices are un-shared and carry their face's normal: same faces, same positions, three equal corner normals
+    = normalize((B - A) x (C - A)), tangents from MikkTSpace, and the oracle renders it like the same mesh handed
+    over with explicit per-corner normals."""
+    P, N, UV, idx = scenes.blob(5, 7, bump=0.3, seed=9)
+
+    def write(name, explicit):
+        w = scenes.GltfWriter()
+        grey = w.material("GREY", (0.6, 0.6, 0.6, 1))
+        emit = w.material("EMIT", (0, 0, 0, 1), emissive=(1, 1, 1), emissive_strength=5)
+        w.doc.setdefault("extensionsUsed", []).append("KHR_materials_emissive_strength")
+        if explicit:
+            tri = P[idx].reshape(-1, 3, 3)
+            fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+            fn = (fn / np.linalg.norm(fn, axis=1, keepdims=True)).astype(np.float32)
+            p = w.primitive(P[idx], np.repeat(fn, 3, axis=0), np.arange(len(idx)), grey, UV[idx])
+        else:
+            p = w.primitive(P, N, idx, grey, UV)
+            del p["attributes"]["NORMAL"]
+        w.node("Blob", mesh=w.mesh("Blob", [p]))
+        w.node("Light", mesh=w.mesh("Light", [scenes.unit_plane(w, emit)]), translation=(0, 0, 3), rotation=(1, 0, 0, 0))
+        w.node("Camera", camera=w.camera(0.7), translation=(0, 0, 5))
+        return host.Scene.load_gltf(w.write(scene_dir, name))
+
+    flat, ref = write("flat_missing", False), write("flat_explicit", True)
+    nf = len(idx) // 3
+    assert len(flat.faces) == len(ref.faces) == nf + 2 and len(flat.vertices) == len(ref.vertices) == 3 * nf + 4
+    assert np.array_equal(flat.faces["vertices"], ref.faces["vertices"]) and (flat.faces["shading"] == 1).all()
+    assert np.array_equal(flat.vertices["position"], ref.vertices["position"])
+    a = flat.vertices["normal"][:3 * nf].reshape(nf, 3, 3)
+    assert np.array_equal(a[:, 0], a[:, 1]) and np.array_equal(a[:, 0], a[:, 2])
+    assert np.abs(flat.vertices["normal"] - ref.vertices["normal"]).max() < 2e-6
+    assert np.abs(np.linalg.norm(flat.vertices["tangent"][:, :3], axis=1) - 1).max() < 1e-5
+    imgs = []
+    for sc in (flat, ref):
+        imgs.append(ob.Oracle(sc, host.BVH(sc), host.LST(sc), 48, 48).render(5, 8, 8))
+    assert np.isfinite(imgs[0]).all() and imgs[0].mean() > 0.01
+    assert np.abs(imgs[0] - imgs[1]).mean() < 0.05 * imgs[1].mean()  # same picture (normals agree to rounding, paths may fork)

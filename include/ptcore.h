@@ -44,7 +44,8 @@ typedef struct {
     uint64_t region_iters[6];
     uint64_t region_lanes[6];
     /* Shader-clock ticks summed over waves: [0] inside the walk slices, [1] node phases,
-     * [2] leaf phases, [3] path-vertex handler, [4] shadow-ray results, [5] unused;
+     * [2] leaf phases, [3] path-vertex handler, [4] shadow-ray results, [5] the handler's two rejection loops
+     * (point on the emitter, BSDF direction: a wave repeats them until its unluckiest lane accepts);
      * wave_ticks = sum of wave lifetimes (includes RNG init and the image write). */
     uint64_t region_ticks[6];
     uint64_t wave_ticks;

@@ -96,7 +96,7 @@ class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
                                     "parked_leaf_only": round(self.node_step_idle[1] / tot, 4),
                                     "awaiting_handler": round(self.node_step_idle[2] / tot, 4)}
         if self.wave_ticks:
-            names = ("walk_slices", "node_phases", "leaf_phases", "vertex_handler", "shadow_results")
+            names = ("walk_slices", "node_phases", "leaf_phases", "vertex_handler", "shadow_results", "rejection_loops")
             d["time_share"] = {nm: round(self.region_ticks[i] / self.wave_ticks, 4) for i, nm in enumerate(names)}
             d["wave_ticks"] = int(self.wave_ticks)
         return d

@@ -1109,10 +1109,12 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                         s_stop = kNoHit;
                     } else {
                         float u1, u2;
+                        unsigned long long tr0 = stamp<COUNT>();
                         do {
                             u1 = rng_uniform(s.rng);
                             u2 = rng_uniform(s.rng);
                         } while (u1 + u2 > 1);
+                        region_time<COUNT>(n, kRegBsdf, tr0, stamp<COUNT>());
                         f3 light_pos = (A + u1 * (B - A)) + u2 * (C - A);
                         nee_dir = normalize(light_pos - position);
                         s.nee_face = (int32_t)gl.face;
@@ -1157,11 +1159,13 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                 // ---- BRDF::sample (brdf.cu:180-192) + next ray (renderer.cu:345-350) ----
                 region_tick<COUNT>(n, kRegBsdf);
                 f3 r;
+                unsigned long long tr1 = stamp<COUNT>();
                 do {
                     r.x = 2 * rng_uniform(s.rng) - 1;
                     r.y = 2 * rng_uniform(s.rng) - 1;
                     r.z = 2 * rng_uniform(s.rng) - 1;
                 } while (dot(r, r) > 1);
+                region_time<COUNT>(n, kRegBsdf, tr1, stamp<COUNT>());
                 f3 wi = normalize(r);
                 wi.z = __builtin_fabsf(wi.z);
                 // both BRDF evaluations of the vertex together (the light's, renderer.cu:338-341, is only used

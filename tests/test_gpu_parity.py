@@ -600,6 +600,23 @@ def test_combine_is_ordered_after_the_render_launches(scene_dir):
         r.close()
 
 
+def test_tiny_and_ragged_images(renderer, cornell_like):
+    """Images smaller than one tile and one pixel wide or high; a launch that continues a running mean from a
+    non-zero previous sample count into a pre-filled accumulator (renderer.cu:398-404); seed 2^31 - 1 (the host
+    loop's seed + 1 then wraps like the reference's int)."""
+    for w, h in ((1, 1), (3, 2), (9, 1), (1, 17), (8, 8), (65, 9)):
+        o = _setup(renderer, cornell_like, w, h)
+        gpu = renderer.render(-3, 5, 2)
+        _assert_images_match(gpu, o.render(-3, 5, 2))
+    o = _setup(renderer, cornell_like, 24, 16)
+    renderer.clear()
+    renderer.render_batch(7, 0, 3)
+    renderer.render_batch(2 ** 31 - 1, 3, 4)
+    cpu, _ = o.render_batch(7, 0, 3)
+    o.render_batch(2 ** 31 - 1, 3, 4, cpu)
+    _assert_images_match(renderer.read_image(), cpu)
+
+
 def test_counters_match_oracle(renderer, cornell_like):
     """Reference-equivalent ray count, samples, shaded hits and bounces are integers that must
     agree exactly; the kernel walks fewer trees than the reference traces rays."""

@@ -126,3 +126,21 @@ def test_png_decoder_equals_stbi_load(gref):
     gref.gref_stbi_free(p)
     got = host.load_png(path)
     assert got.shape == (1024, 1024, 4) and np.array_equal(got.reshape(-1), want)
+
+
+def test_png_writer_output_decodes_in_stb_image(gref, tmp_path):
+    """render.png as the CLI writes it (pth_write_image: tonemap + own deflate / PNG encoder), read back by the
+    reference's stb_image: the pixels are the tonemapped buffer, byte for byte (the reference writes with
+    stb_image_write, whose exact file bytes depend on its deflate heuristics and are not the contract)."""
+    from oracle import binding as ob
+    rng = np.random.RandomState(5)
+    img = (rng.rand(67, 129, 3).astype(np.float32) ** 3) * 4.0
+    path = str(tmp_path / "render.png")
+    host.write_image(img, path)
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    p = gref.gref_stbi_load(path.encode(), C.byref(w), C.byref(h), C.byref(c))
+    assert p and (w.value, h.value, c.value) == (129, 67, 3)
+    got = np.frombuffer((C.c_uint8 * (w.value * h.value * 4)).from_address(p), np.uint8).reshape(67, 129, 4).copy()
+    gref.gref_stbi_free(p)
+    assert (got[..., 3] == 255).all()
+    assert np.array_equal(got[..., :3], ob.tonemap_rgb8(img))

@@ -1,0 +1,42 @@
+"""N = 2 with the REAL kernel: two ranks (torch.distributed.run, one process each, both on the box's one GPU, so
+the collective is gloo's - RCCL refuses two ranks on one device) render their batches with render_sharded and
+combine them with the single sum-reduce; the result equals the one-rank batch loop up to fp32 summation order.
+(The RCCL call itself runs under test_sharded_render_through_rccl_one_rank and test_group_render_one_device.)
+
+Collected first on purpose (file name): the ranks are child processes, and this pool forbids starting programs
+from a process that has already initialised the GPU.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import _ffi, core
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_render_and_combine_on_the_gpu(tmp_path):
+    if core.CONTEXTS_CREATED:
+        pytest.skip("GPU already initialised in this process; run this file first or alone")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path)
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(_ffi.REPO_ROOT, "tests", "sharded_worker.py"), out],
+                         capture_output=True, text=True, timeout=170, env=env)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert open(os.path.join(out, "rank0.txt")).read().split() == ["2", "14"]  # batches 0, 2, 4, 6: 4 + 4 + 4 + 2 samples
+    assert open(os.path.join(out, "rank1.txt")).read().split() == ["2", "12"]  # batches 1, 3, 5
+    combined, single = np.load(os.path.join(out, "combined.npy")), np.load(os.path.join(out, "single.npy"))
+    assert combined.shape == single.shape == (136, 200, 3) and np.isfinite(single).all() and np.isfinite(combined).all()
+    err = np.abs(combined.astype(np.float64) - single).max()
+    scale = np.abs(single).max()
+    assert err <= 2e-6 * scale, (err, scale)  # same samples; flat weighted sum against the running mean
+    assert np.abs(combined - single).mean() / np.abs(single).mean() <= 1e-6
+    assert not np.array_equal(combined, np.zeros_like(combined)) and single.mean() > 0.1

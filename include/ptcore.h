@@ -112,8 +112,9 @@ int pt_render_batch(pt_context *ctx, int seed, int previous_samples, int current
 int pt_render_batch_into(pt_context *ctx, float *device_img, void *stream, int seed,
                          int previous_samples, int current_samples);
 
-/* NO COUNTERPART IN THE REFERENCE. For callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc. The same launch as pt_render_batch_into,
+/* NO COUNTERPART IN THE REFERENCE. For callers that cannot allocate device memory: tight serving loops, harnesses
+ * that forbid hipMalloc, code that runs between a graph's captures. (Not for use UNDER stream capture: the launch
+ * records timing events and decides the tile order on the host at call time, neither of which a replay repeats.) The same launch as pt_render_batch_into,
  * with two differences: (1) the image size, exposure and clear colour come with the call (pt_configure, whose
  * job is to allocate, need not have been called, and is not disturbed if it was); (2) the kernels' per-tile
  * scratch (RNG base states, tile costs, sort keys, launch order: 44 bytes per 8x8 tile) lives in ONE
@@ -150,6 +151,20 @@ void pt_group_destroy(pt_group *group);
 int pt_group_size(pt_group *group);
 pt_context *pt_group_context(pt_group *group, int rank);
 int pt_group_render(pt_group *group, int seed, int samples, int samples_every_update);
+
+/* The plan pt_group_render follows, as a pure function (no device, no group; callable on a machine without a
+ * GPU): batch b of the reference's loop (src/main.cu:101-102) goes to rank b mod ranks with seed + b and
+ * continues that rank's running mean. Writes at most `capacity` entries to `batches` (may be NULL) and one
+ * weight per rank to `weights` (may be NULL): the rank's share of the samples, 0 for a rank without a batch; the
+ * shares sum to 1. Returns the number of batches of the whole job, or -1 on bad arguments. */
+typedef struct {
+    int index;            /* b */
+    int rank;             /* b mod ranks */
+    int seed;             /* seed + b */
+    int previous_samples; /* samples this rank has rendered before this batch */
+    int current_samples;  /* min(samples_every_update, samples left) */
+} pt_group_batch;
+int pt_group_plan(int seed, int samples, int samples_every_update, int ranks, pt_group_batch *batches, int capacity, float *weights);
 
 /* ---- verification / measurement hooks (no counterpart in the reference) ---- */
 
@@ -188,6 +203,19 @@ float pt_kernel_ms(pt_context *ctx, int launches_back);
  * (pt_counters.redone_walks), so the choice never shows in a pixel. Faces on the same three points would
  * make every ray through them do that: pt_bvh_upload looks for such faces and then answers 2 at once. */
 int pt_walk_tree(pt_context *ctx);
+
+/* NO COUNTERPART IN THE REFERENCE. Which arithmetic the context's render launches compute in.
+ * PT_ARITHMETIC_EXACT (default, the gate): every float operation rounds as the CPU restatement of the reference's
+ * kernel does (no contraction, IEEE division and square root); images are bit-identical to the oracle's.
+ * PT_ARITHMETIC_FAST: the same kernels compiled a second time with tolerance arithmetic (fp contraction on, the
+ * hardware's 1-ulp reciprocal / root, no tie bookkeeping in the walk): what nvcc's default contraction gives the
+ * reference itself (bvh.cu:222-237, intersect.cu:12-81, mathops.h:114-121). Same RNG stream bit for bit; primary
+ * hits and image agree with the exact variant within the tolerances stated in tests/test_gpu_tolerance.py.
+ * PT_ARITHMETIC=fast in the environment makes it the default of new contexts. Waits for the context's stream. */
+#define PT_ARITHMETIC_EXACT 0
+#define PT_ARITHMETIC_FAST 1
+int pt_set_arithmetic(pt_context *ctx, int arithmetic);
+int pt_arithmetic(pt_context *ctx);
 
 /* Bytes of device memory held by the context (scene + BVH + LST + image). */
 uint64_t pt_device_footprint(pt_context *ctx);

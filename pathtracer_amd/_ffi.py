@@ -102,6 +102,10 @@ class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
         return d
 
 
+class GroupBatch(C.Structure):  # pt_group_batch (include/ptcore.h)
+    _fields_ = [("index", C.c_int), ("rank", C.c_int), ("seed", C.c_int), ("previous_samples", C.c_int), ("current_samples", C.c_int)]
+
+
 VEC3 = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")]
 VEC4 = VEC3 + [("w", "<f4")]
 VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("texcoord0", "<f4", 3), ("tangent", "<f4", 4)])
@@ -203,6 +207,9 @@ def core_lib():
     L.pt_kernel_ms.argtypes = [C.c_void_p, C.c_int]
     L.pt_kernel_ms.restype = C.c_float
     L.pt_walk_tree.argtypes = [C.c_void_p]
+    L.pt_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
+    L.pt_arithmetic.argtypes = [C.c_void_p]
+    L.pt_group_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GroupBatch), C.c_int, C.POINTER(C.c_float)]
     L.pt_device_footprint.argtypes = [C.c_void_p]
     L.pt_device_footprint.restype = C.c_uint64
     _core = L

@@ -136,6 +136,15 @@ class Renderer:
         """HIP-event duration of an earlier render launch (0 = the most recent one)."""
         return float(self._lib.pt_kernel_ms(self._ctx, int(launches_back)))
 
+    ARITHMETIC = {"exact": 0, "fast": 1}
+
+    def set_arithmetic(self, name):
+        """"exact" (default: bit-identical to the CPU oracle) or "fast" (tolerance arithmetic), include/ptcore.h."""
+        _check(self._lib.pt_set_arithmetic(self._ctx, self.ARITHMETIC[name]))
+
+    def arithmetic(self):
+        return "fast" if int(self._lib.pt_arithmetic(self._ctx)) == 1 else "exact"
+
     def walk_tree(self):
         """2 = binary tree, 4 = four-wide, 0 = not chosen yet (see include/ptcore.h)."""
         return int(self._lib.pt_walk_tree(self._ctx))
@@ -153,6 +162,19 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+def group_plan(seed, samples, samples_every_update, ranks):
+    """pt_group_plan: ([(index, rank, seed, previous_samples, current_samples)], [weight per rank]). Pure host
+    arithmetic: needs the library, not a GPU."""
+    lib = _ffi.core_lib()
+    n = lib.pt_group_plan(int(seed), int(samples), int(samples_every_update), int(ranks), None, 0, None)
+    if n < 0:
+        raise CoreError(lib.pt_last_error().decode("utf-8", "replace"))
+    batches = (_ffi.GroupBatch * n)()
+    weights = (C.c_float * int(ranks))()
+    lib.pt_group_plan(int(seed), int(samples), int(samples_every_update), int(ranks), batches, n, weights)
+    return ([(b.index, b.rank, b.seed, b.previous_samples, b.current_samples) for b in batches], [float(w) for w in weights])
 
 
 class Group:

@@ -48,37 +48,15 @@ namespace ptc {
 
 #define PT_DEV __device__ __forceinline__
 
+#ifndef PT_FAST
+#define PT_FAST 0 /* 1: tolerance arithmetic (contraction on, hardware reciprocal / root, no tie bookkeeping) */
+#endif
 #ifndef PT_BLOCK
 #define PT_BLOCK 64 /* threads per workgroup: one wave64 = one 8x8 pixel tile */
 #endif
 constexpr int kBlock = PT_BLOCK;
 
-
-struct f3 {
-    float x, y, z;
-};
-PT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
-PT_DEV f3 ld3(const float *p) { return f3{p[0], p[1], p[2]}; }
-PT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-PT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
-PT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
-PT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
-PT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-PT_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
-PT_DEV float rcp_exact(float s) { return 1.0f / s; } // == (float)(1.0 / (double)s): division is safe under double rounding
-PT_DEV f3 operator/(f3 a, float s) { return a * rcp_exact(s); }
-PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
-PT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-PT_DEV float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
-PT_DEV f3 normalize(f3 a) { return a * rcp_exact(length(a)); }
-PT_DEV float luminance(f3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
-// glibc fmaxf/fminf selection rules (sign of zero and NaN handling match the host)
-PT_DEV float max_gl(float x, float y) { return (x >= y || y != y) ? x : y; }
-PT_DEV float min_gl(float x, float y) { return (x <= y || y != y) ? x : y; }
-
-// 1e-12 is not a float; these are the float thresholds equivalent to the
-// reference's double compares (intersect.cu:56,65,73; renderer.cu:149).
-#define PT_EPS_UP 1.0000001044244144e-12f /* 0x2b8cbccd: smallest float >= 1e-12 */
+// ---- what the host side (ptcore.hip) and both arithmetic variants of the kernels share -------------------
 
 struct Texture {
     const void *texels;
@@ -117,6 +95,59 @@ struct KernelParams {
     uint32_t *tile_cost;
     uint32_t *tile_rng; // [tiles][8]: RNG state (v0..v4, d) of each render tile's first pixel for this launch's seed
 };
+
+// Everything below exists twice in libptcore.so, compiled from this one source: ptc::exact (ptcore.hip, built with
+// -ffp-contract=off: every float operation rounds as the reference's restatement does, the gate) and ptc::fast
+// (kernels_fast.hip, built with -DPT_FAST=1 -ffp-contract=fast: tolerance arithmetic). pt_set_arithmetic picks
+// one per context through the table in launch.h.
+#if PT_FAST
+#define PT_ARITH_NS fast
+#else
+#define PT_ARITH_NS exact
+#endif
+namespace PT_ARITH_NS {
+
+
+struct f3 {
+    float x, y, z;
+};
+PT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+PT_DEV f3 ld3(const float *p) { return f3{p[0], p[1], p[2]}; }
+PT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+// Division and square root. Exact arithmetic (the default, PT_FAST == 0): IEEE, correctly rounded, as the reference's
+// host-side restatement computes them (hipcc expands 1.0f / x into 11 and sqrtf into 16 instructions). Tolerance
+// arithmetic (PT_FAST == 1, kernels_fast.hip): the hardware's 1-ulp v_rcp_f32 / v_sqrt_f32 / v_rsq_f32.
+#if PT_FAST
+PT_DEV float rcp_exact(float s) { return __builtin_amdgcn_rcpf(s); }
+PT_DEV float pt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+PT_DEV float pt_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+PT_DEV float rcp_exact(float s) { return 1.0f / s; } // == (float)(1.0 / (double)s): division is safe under double rounding
+PT_DEV float pt_div(float a, float b) { return a / b; }
+PT_DEV float pt_sqrt(float x) { return __builtin_sqrtf(x); }
+#endif
+PT_DEV f3 operator/(f3 a, float s) { return a * rcp_exact(s); }
+PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+PT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PT_DEV float length(f3 a) { return pt_sqrt(dot(a, a)); }
+#if PT_FAST
+PT_DEV f3 normalize(f3 a) { return a * __builtin_amdgcn_rsqf(dot(a, a)); }
+#else
+PT_DEV f3 normalize(f3 a) { return a * rcp_exact(length(a)); }
+#endif
+PT_DEV float luminance(f3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
+// glibc fmaxf/fminf selection rules (sign of zero and NaN handling match the host)
+PT_DEV float max_gl(float x, float y) { return (x >= y || y != y) ? x : y; }
+PT_DEV float min_gl(float x, float y) { return (x <= y || y != y) ? x : y; }
+
+// 1e-12 is not a float; these are the float thresholds equivalent to the
+// reference's double compares (intersect.cu:56,65,73; renderer.cu:149).
+#define PT_EPS_UP 1.0000001044244144e-12f /* 0x2b8cbccd: smallest float >= 1e-12 */
 
 // ---- XORWOW ------------------------------------------------------------------------
 
@@ -212,9 +243,18 @@ PT_DEV void rng_normal_pair(Rng &s, float *first, float *second) {
     const float two_pi_scale = 2.3283064e-10f * 6.2831855f;
     float u = (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
     float v = (float)y * two_pi_scale + (two_pi_scale / 2.0f);
+#if PT_FAST
+    // v_log_f32 is log2, v_sin_f32 / v_cos_f32 take revolutions (the fast intrinsics curand_normal itself uses on
+    // the device are of this kind): the u32 stream is untouched, the two floats are within 1e-6 of the exact form's
+    (void)v;
+    float r = pt_sqrt(-2.0f * (__builtin_amdgcn_logf(u) * 0.69314718056f));
+    float turn = (float)y * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+    float sn = __builtin_amdgcn_sinf(turn), cs = __builtin_amdgcn_cosf(turn);
+#else
     float r = __builtin_sqrtf(-2.0f * pt_logf(u));
     float sn, cs;
     pt_sincosf(v, &sn, &cs);
+#endif
     *first = r * sn;
     *second = r * cs;
 }
@@ -240,7 +280,7 @@ PT_DEV float4 fetch_texel(const Texture &t, int x, int y) {
     size_t at = (size_t)y * (size_t)t.width + (size_t)x;
     if (t.isFloat) return ((const float4 *)t.texels)[at];
     uchar4 p = ((const uchar4 *)t.texels)[at];
-    return make_float4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
+    return make_float4(pt_div((float)p.x, 255.0f), pt_div((float)p.y, 255.0f), pt_div((float)p.z, 255.0f), pt_div((float)p.w, 255.0f));
 }
 __device__ __noinline__ float4 sample_texture(const Texture *tp, float u, float v) {
     Texture t = *tp;
@@ -353,8 +393,13 @@ PT_DEV float slab(f3 bmin, f3 bmax, f3 o, f3 rinv, float limit) {
 // operand is NaN (signed zeros only differ in sign, which no later compare sees); NaN needs
 // 0 * inf, i.e. an infinite reciprocal, and those rays take slab() instead.
 PT_DEV float slab_fast(f3 bmin, f3 bmax, f3 o, f3 rinv, float limit) {
+#if PT_FAST /* here `o` is origin * rinv: one fused multiply-add per plane */
+    f3 t1 = mk3(__builtin_fmaf(bmin.x, rinv.x, -o.x), __builtin_fmaf(bmin.y, rinv.y, -o.y), __builtin_fmaf(bmin.z, rinv.z, -o.z));
+    f3 t2 = mk3(__builtin_fmaf(bmax.x, rinv.x, -o.x), __builtin_fmaf(bmax.y, rinv.y, -o.y), __builtin_fmaf(bmax.z, rinv.z, -o.z));
+#else
     f3 t1 = (bmin - o) * rinv;
     f3 t2 = (bmax - o) * rinv;
+#endif
     float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t1.x, t2.x), __builtin_fminf(t1.y, t2.y)),
                                  __builtin_fminf(t1.z, t2.z));
     float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t1.x, t2.x), __builtin_fmaxf(t1.y, t2.y)),
@@ -427,8 +472,10 @@ struct Walk {
 // to be compared with the best so far. Whichever of the two does not end up as the best is a candidate
 // for "nearest other". The distance a shadow walk starts from is not a hit and does not count.
 PT_DEV void note_other(HitLite &h, float t) {
+#if !PT_FAST /* tolerance arithmetic keeps no second distance: ties within rounding go to whichever is tested first */
     const float best = h.face >= 0 ? h.t : kNoHit;
     h.t2 = __builtin_fminf(h.t2, __builtin_fmaxf(t, best));
+#endif
 }
 
 // Moeller-Trumbore on one pre-gathered triangle (src/intersect.cu:12-81, non-culling branch)
@@ -438,7 +485,7 @@ PT_DEV void test_triangle(float4 a, float4 b, float4 c, f3 o, f3 d, float t_stop
     f3 pvec = cross(d, e2);
     float det = dot(e1, pvec);
     if (det > -PT_EPS_UP && det < PT_EPS_UP) return;
-    float inv_det = 1.0f / det;
+    float inv_det = rcp_exact(det);
     f3 tvec = o - v0;
     float u = dot(tvec, pvec) * inv_det;
     if (u <= -PT_EPS_UP || u > 1.0f) return;
@@ -469,7 +516,7 @@ PT_DEV void test_triangle_pair(float4 a0, float4 b0, float4 c0, float4 a1, float
     // pvec = cross(d, e2)
     v2f px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
     v2f det = e1x * px + (e1y * py + e1z * pz);
-    v2f inv_det = {1.0f / det.x, 1.0f / det.y};
+    v2f inv_det = {rcp_exact(det.x), rcp_exact(det.y)};
     v2f tx = v2f{o.x, o.x} - v0x, ty = v2f{o.y, o.y} - v0y, tz = v2f{o.z, o.z} - v0z;
     v2f u = (tx * px + (ty * py + tz * pz)) * inv_det;
     // qvec = cross(tvec, e1)
@@ -551,11 +598,14 @@ PT_DEV void walk_begin(const KernelParams &P, f3 d, float &t_init, Walk &w) {
 
 template <bool COUNT, bool WIDE, class STK>
 PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_stop, STK &stack, Walk &w, Tally &n) {
-    f3 rinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    f3 rinv = mk3(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
     const float inf = __builtin_inff();
     const bool inf_rinv = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
     const bool seq = t_init < 0.0f;                  // sequential walk (see kCullSlack)
     const bool exact = !WIDE || inf_rinv || seq;      // walks the binary tree
+#if PT_FAST
+    const f3 orr = o * rinv; // (NaN where 0 * inf: only for rays that take the select-form test below, which does not use it)
+#endif
     constexpr int slice = WIDE ? PT_SLICE_WIDE : PT_SLICE;
     int steps = 0; // wave-uniform: every exit test below is a ballot or this counter
     for (;;) {
@@ -588,14 +638,25 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
                     float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], cr = np[6];
                     // (b - o) * rinv for the eight planes of two children at a time: packed fp32 math
                     // (v_pk_add_f32 / v_pk_mul_f32 round like the scalar forms)
-                    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
                     const v2f rx = {rinv.x, rinv.x}, ry = {rinv.y, rinv.y}, rz = {rinv.z, rinv.z};
+#if PT_FAST
+                    // b * rinv - o * rinv: one v_pk_fma_f32 per pair of planes (o * rinv once per slice)
+                    const v2f ox = {orr.x, orr.x}, oy = {orr.y, orr.y}, oz = {orr.z, orr.z};
+                    v2f ax01 = v2f{lx.x, lx.y} * rx - ox, ax23 = v2f{lx.z, lx.w} * rx - ox;
+                    v2f ay01 = v2f{ly.x, ly.y} * ry - oy, ay23 = v2f{ly.z, ly.w} * ry - oy;
+                    v2f az01 = v2f{lz.x, lz.y} * rz - oz, az23 = v2f{lz.z, lz.w} * rz - oz;
+                    v2f bx01 = v2f{hx.x, hx.y} * rx - ox, bx23 = v2f{hx.z, hx.w} * rx - ox;
+                    v2f by01 = v2f{hy.x, hy.y} * ry - oy, by23 = v2f{hy.z, hy.w} * ry - oy;
+                    v2f bz01 = v2f{hz.x, hz.y} * rz - oz, bz23 = v2f{hz.z, hz.w} * rz - oz;
+#else
+                    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
                     v2f ax01 = (v2f{lx.x, lx.y} - ox) * rx, ax23 = (v2f{lx.z, lx.w} - ox) * rx;
                     v2f ay01 = (v2f{ly.x, ly.y} - oy) * ry, ay23 = (v2f{ly.z, ly.w} - oy) * ry;
                     v2f az01 = (v2f{lz.x, lz.y} - oz) * rz, az23 = (v2f{lz.z, lz.w} - oz) * rz;
                     v2f bx01 = (v2f{hx.x, hx.y} - ox) * rx, bx23 = (v2f{hx.z, hx.w} - ox) * rx;
                     v2f by01 = (v2f{hy.x, hy.y} - oy) * ry, by23 = (v2f{hy.z, hy.w} - oy) * ry;
                     v2f bz01 = (v2f{hz.x, hz.y} - oz) * rz, bz23 = (v2f{hz.z, hz.w} - oz) * rz;
+#endif
                     const float lim = w.h.t * kCullSlack;
                     float t0 = slab_planes(ax01.x, ay01.x, az01.x, bx01.x, by01.x, bz01.x, lim);
                     float t1 = slab_planes(ax01.y, ay01.y, az01.y, bx01.y, by01.y, bz01.y, lim);
@@ -642,8 +703,13 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
                     float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     float t1, t2;
                     if (!inf_rinv) {
+#if PT_FAST
+                        t1 = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), orr, rinv, w.h.t * kCullSlack);
+                        t2 = slab_fast(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), orr, rinv, w.h.t * kCullSlack);
+#else
                         t1 = slab_fast(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, w.h.t);
                         t2 = slab_fast(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, w.h.t);
+#endif
                     } else {
                         t1 = slab(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, rinv, w.h.t);
                         t2 = slab(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, rinv, w.h.t);
@@ -714,7 +780,7 @@ struct Brdf {
 PT_DEV float g1_schlick_ggx(float n_dot_v, float roughness) {
     float alpha = roughness * roughness;
     float k = 0.5f * alpha; // 0.5 * alpha in double is exact
-    return n_dot_v / (n_dot_v * (1.0f - k) + k);
+    return pt_div(n_dot_v, n_dot_v * (1.0f - k) + k);
 }
 
 // BRDF::eval for one direction, as the reference writes it. The kernel evaluates the two directions of
@@ -724,14 +790,14 @@ PT_DEV f3 brdf_eval(Brdf b, f3 wo, f3 wi) {
     float cos_theta_wi = max_gl(wi.z, 0.0f);
     f3 l = wi, v = wo;
     f3 h = normalize(l + v);
-    float f0d = (float)(0.16 * (double)b.specular * (double)b.specular);
+    float f0d = PT_FAST ? 0.16f * b.specular * b.specular : (float)(0.16 * (double)b.specular * (double)b.specular);
     f3 F0_diel = mk3(1, 1, 1) * f0d;
     f3 F0 = (b.baseColor * b.metallic) + (F0_diel * (1 - b.metallic));
     float x = 1 - dot(v, h);
     f3 F = F0 + ((((((mk3(1, 1, 1) - F0) * x) * x) * x) * x) * x);
     float alpha = b.roughness * b.roughness;
     float bb = h.z * h.z * (alpha * alpha - 1.0f) + 1.0f;
-    float D = alpha * alpha / (PT_PI_F * bb * bb);
+    float D = pt_div(alpha * alpha, PT_PI_F * bb * bb);
     float G = g1_schlick_ggx(l.z, b.roughness) * g1_schlick_ggx(v.z, b.roughness);
     float n_dot_v = max_gl(v.z, 0.001f);
     float n_dot_l = max_gl(l.z, 0.001f);
@@ -755,9 +821,13 @@ __device__ __noinline__ BrdfPair brdf_eval_pair(Brdf b, f3 wo, f3 wi0, f3 wi1) {
     // h = normalize(l + v)
     v2f sx = lx + v2f{v.x, v.x}, sy = ly + v2f{v.y, v.y}, sz = lz + v2f{v.z, v.z};
     v2f len2 = sx * sx + (sy * sy + sz * sz);
+    #if PT_FAST
+    v2f inv_len = {__builtin_amdgcn_rsqf(len2.x), __builtin_amdgcn_rsqf(len2.y)};
+#else
     v2f inv_len = {rcp_exact(__builtin_sqrtf(len2.x)), rcp_exact(__builtin_sqrtf(len2.y))};
+#endif
     v2f hx = sx * inv_len, hy = sy * inv_len, hz = sz * inv_len;
-    float f0d = (float)(0.16 * (double)b.specular * (double)b.specular);
+    float f0d = PT_FAST ? 0.16f * b.specular * b.specular : (float)(0.16 * (double)b.specular * (double)b.specular);
     f3 F0_diel = mk3(1, 1, 1) * f0d;
     f3 F0 = (b.baseColor * b.metallic) + (F0_diel * (1 - b.metallic));
     v2f x = v2f{1.0f, 1.0f} - (v2f{v.x, v.x} * hx + (v2f{v.y, v.y} * hy + v2f{v.z, v.z} * hz));
@@ -769,7 +839,7 @@ __device__ __noinline__ BrdfPair brdf_eval_pair(Brdf b, f3 wo, f3 wi0, f3 wi1) {
     float a2 = alpha * alpha, a2m1 = alpha * alpha - 1.0f;
     v2f bb = hz * hz * v2f{a2m1, a2m1} + v2f{1.0f, 1.0f};
     v2f denom = v2f{PT_PI_F, PT_PI_F} * bb * bb;
-    v2f D = {a2 / denom.x, a2 / denom.y};
+    v2f D = {pt_div(a2, denom.x), pt_div(a2, denom.y)};
     float g1v = g1_schlick_ggx(v.z, b.roughness);
     v2f G = v2f{g1_schlick_ggx(wi0.z, b.roughness), g1_schlick_ggx(wi1.z, b.roughness)} * v2f{g1v, g1v};
     float n_dot_v = max_gl(v.z, 0.001f);
@@ -777,7 +847,7 @@ __device__ __noinline__ BrdfPair brdf_eval_pair(Brdf b, f3 wo, f3 wi0, f3 wi1) {
     v2f four_nn = v2f{4.0f * n_dot_v, 4.0f * n_dot_v} * n_dot_l;
     v2f inv_four_nn = {rcp_exact(four_nn.x), rcp_exact(four_nn.y)};
     v2f spx = ((Fx * D) * G) * inv_four_nn, spy = ((Fy * D) * G) * inv_four_nn, spz = ((Fz * D) * G) * inv_four_nn;
-    float dielectric = (float)(1.0 - (double)b.metallic);
+    float dielectric = PT_FAST ? 1.0f - b.metallic : (float)(1.0 - (double)b.metallic);
     const v2f one = {1.0f, 1.0f}, dd = {dielectric, dielectric}, ipi = {PT_1_PI_F, PT_1_PI_F};
     v2f dfx = ((v2f{b.baseColor.x, b.baseColor.x} * (one - Fx)) * dd) * ipi;
     v2f dfy = ((v2f{b.baseColor.y, b.baseColor.y} * (one - Fy)) * dd) * ipi;
@@ -797,7 +867,7 @@ PT_DEV f3 rgb_to_radiometric(f3 color, float intensity) {
     f3 cn = mk3(1, 1, 1);
     if (m >= PT_EPS_UP) cn = color / m;
     float photometric = intensity * m;
-    float alpha = (float)((double)photometric / (683.0 * (double)luminance(cn)));
+    float alpha = (float)((double)photometric / (683.0 * (double)luminance(cn))); // (not on the kernel path: lights are baked on the host)
     return cn * alpha;
 }
 
@@ -833,7 +903,7 @@ PT_DEV float area_pdf(const GShade *s, f3 dir, float t, f3 *normal_out) {
     float area = 0.5f * len;
     float cos_theta_y = __builtin_fabsf(dot(normal, dir));
     if (normal_out) *normal_out = normal;
-    return t * t / (area * cos_theta_y);
+    return pt_div(t * t, area * cos_theta_y);
 }
 
 PT_DEV uint32_t pixel_of_thread(const KernelParams &P, int *px, int *py) {
@@ -862,6 +932,7 @@ PT_DEV uint32_t pixel_of_thread(const KernelParams &P, int *px, int *py) {
     return ty * ntx + tx;
 }
 
+#if !PT_FAST /* integer-only helper kernels: one copy, in the exact translation unit */
 // Launch order for the next launch. key = (cost class, position in the static order): tiles are
 // ranked heaviest class first, and inside a class they keep the static XCD-interleaved order, so
 // neighbouring tiles still run together on one XCD (a plain sort by cost scatters them, which costs
@@ -897,6 +968,8 @@ __global__ void __launch_bounds__(64) tile_order_kernel(const uint32_t *__restri
     uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i < n) order[rank[i]] = i;
 }
+
+#endif // !PT_FAST
 
 PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {
     f3 U = ld3(P.cam_u), V = ld3(P.cam_v), W = ld3(P.cam_w);
@@ -936,8 +1009,8 @@ PT_DEV void start_sample(const KernelParams &P, int px, int py, Path &s, Tally &
     rng_normal_pair(s.rng, &nx, &ny);
     float sx = (float)px + 0.33f * nx;
     float sy = (float)py + 0.33f * ny;
-    float u = (2 * sx - (float)P.width) / (float)P.height;
-    float v = (2 * sy - (float)P.height) / (float)P.height;
+    float u = pt_div(2 * sx - (float)P.width, (float)P.height);
+    float v = pt_div(2 * sy - (float)P.height, (float)P.height);
     camera_ray(P, u, v, &s.ro, &s.rd);
     s.light = mk3(0, 0, 0);
     s.thr = mk3(1, 1, 1);
@@ -997,11 +1070,11 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                 float p_als = area_pdf(&gs, s.rd, hit.t, nullptr);
                 for (uint32_t k = gs.flags >> 8; k > 0; k--) p_direct += p_als;
             }
-            p_direct = p_direct / (float)P.lst_count;
+            p_direct = pt_div(p_direct, (float)P.lst_count);
         }
         float pdf = brdf_pdf();
-        float weight = pdf / (p_direct + pdf);
-        s.thr = s.thr * (s.f_cos_next * (weight / (pdf * s.rr_prob)));
+        float weight = pt_div(pdf, p_direct + pdf);
+        s.thr = s.thr * (s.f_cos_next * pt_div(weight, pdf * s.rr_prob));
         s.pending = false;
     }
     if (!sh) {
@@ -1009,8 +1082,8 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
         if (P.clear_texture >= 0) {
             float phi = pt_atan2f(s.rd.z, s.rd.x);
             float theta = pt_acosf(min_gl(max_gl(s.rd.y, -1.0f), 1.0f));
-            float eu = (float)(((double)phi + PT_PI_D) / (2.0f * PT_PI_D));
-            float ev = (float)((double)theta / PT_PI_D);
+            float eu = PT_FAST ? (phi + PT_PI_F) * (0.5f * PT_1_PI_F) : (float)(((double)phi + PT_PI_D) / (2.0f * PT_PI_D));
+            float ev = PT_FAST ? theta * PT_1_PI_F : (float)((double)theta / PT_PI_D);
             float4 t = sample_texture(P.textures + P.clear_texture, eu, ev);
             clear = clear * mk3(t.x, t.y, t.z);
         }
@@ -1019,7 +1092,7 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
     } else {
         // ---- hit record (intersect.cu:100-198) ----
         float u = hit.u, v = hit.v;
-        float w = (float)(1.0 - (double)u - (double)v);
+        float w = PT_FAST ? 1.0f - u - v : (float)(1.0 - (double)u - (double)v);
         f3 position = (w * ld3(gs.pos[0]) + u * ld3(gs.pos[1])) + v * ld3(gs.pos[2]);
         f3 baseColor = mk3(m.baseColorFactor[0], m.baseColorFactor[1], m.baseColorFactor[2]);
         float alpha = m.baseColorFactor[3];
@@ -1090,7 +1163,7 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                 if (P.lst_count != 0) {
                     int node_index = (int)((float)P.lst_count * rng_uniform(s.rng));
                     GLight gl = P.glights[(uint32_t)node_index % P.lst_count];
-                    float p_lss = 1.0f / (float)P.lst_count; // times the area pdf for an emitter
+                    float p_lss = rcp_exact((float)P.lst_count); // times the area pdf for an emitter
                     f3 radiance = ld3(gl.radiance);
                     f3 A = ld3(gl.a), B = ld3(gl.b), C = ld3(gl.c);
                     bool can_see = true; // false: the reference's walk cannot end on this s.light
@@ -1126,7 +1199,7 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                         float det = dot(e1, pvec);
                         float t_f = -1.0f;
                         if (!(det > -PT_EPS_UP && det < PT_EPS_UP)) {
-                            float inv_det = 1.0f / det;
+                            float inv_det = rcp_exact(det);
                             f3 tvec = so - A;
                             float uu = dot(tvec, pvec) * inv_det;
                             if (!(uu <= -PT_EPS_UP || uu > 1.0f)) {
@@ -1140,7 +1213,7 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                             s_stop = t_f - t_f * kBand;
                             // sample_area_light, renderer.cu:131-133, with the emitter's baked normal and area
                             float cos_theta_y = __builtin_fabsf(dot(ld3(gl.normal), nee_dir));
-                            float p_als = t_f * t_f / (gl.area * cos_theta_y);
+                            float p_als = pt_div(t_f * t_f, gl.area * cos_theta_y);
                             p_lss = p_lss * p_als;
                         } else {
                             can_see = false;
@@ -1176,8 +1249,8 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
                 if (shadow) {
                     float p_brdf = brdf_pdf();
                     f3 direct = f_cos * nee_radiance;
-                    float weight = nee_p / (nee_p + p_brdf);
-                    s.direct_c = ((weight / nee_p) * s.thr) * direct;
+                    float weight = pt_div(nee_p, nee_p + p_brdf);
+                    s.direct_c = (pt_div(weight, nee_p) * s.thr) * direct;
                     // A light below the vertex's horizon (cos = 0) or a black throughput makes the term an
                     // exact zero; light + 0 is light whatever the walk would find, so the walk is not taken.
                     // (NaN and infinity are not zero: those vertices keep their walk and the reference's result.)
@@ -1271,6 +1344,7 @@ PT_DEV void ring_get(const uint32_t *ring, uint32_t pos, uint32_t &q, Rng &g, f3
 // tiles per wave (the work per wave is a chain of scalar row loads; more, emptier waves hide their
 // latency better than 256 full ones).
 constexpr uint32_t kTileRngLanes = 16;
+#if !PT_FAST
 __global__ void __launch_bounds__(64) tile_rng_kernel(KernelParams P, uint32_t ntx, uint32_t nty, uint32_t rows) {
     uint32_t t = blockIdx.x * kTileRngLanes + threadIdx.x;
     bool valid = threadIdx.x < kTileRngLanes && t < ntx * nty;
@@ -1283,6 +1357,7 @@ __global__ void __launch_bounds__(64) tile_rng_kernel(KernelParams P, uint32_t n
         out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3]; out[4] = v[4]; out[5] = d;
     }
 }
+#endif // !PT_FAST
 
 // One wave renders a tile of kPool = 8 * ROWS pixels with 64 lanes. With ROWS = 16 a lane does NOT own a pixel for the whole
 // launch: after PT_SWAP_EVERY samples it swaps its pixel (RNG state, sum, count: 40 bytes) with the
@@ -1366,8 +1441,8 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
                 pool_pixel<ROWS>(tx, ty, (uint32_t)q, &px, &py);
                 float *p = img + 3 * ((size_t)py * (size_t)P.width + (size_t)px);
                 f3 last = mk3(p[0], p[1], p[2]);
-                f3 next = last * ((float)P.previous_samples / (float)total_samples) +
-                          mean * ((float)P.current_samples / (float)total_samples);
+                f3 next = last * pt_div((float)P.previous_samples, (float)total_samples) +
+                          mean * pt_div((float)P.current_samples, (float)total_samples);
                 p[0] = next.x;
                 p[1] = next.y;
                 p[2] = next.z;
@@ -1425,7 +1500,7 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         bool finished = active && wk.ref == kDone && wk.pleaf == 0;
         // A speculative walk whose winner has another candidate within rounding of it starts over as a sequential
         // one (see kCullSlack). Not after an early exit: whatever is nearest there, the light is hidden.
-        if (finished && s.t_init > 0.0f && !wk.h.early && wk.h.face >= 0 && wk.h.t2 <= wk.h.t * kNearHi) {
+        if (!PT_FAST && finished && s.t_init > 0.0f && !wk.h.early && wk.h.face >= 0 && wk.h.t2 <= wk.h.t * kNearHi) {
             s.t_init = -s.t_init;
             walk_reset(P.root, -s.t_init, wk);
             finished = false;
@@ -1522,8 +1597,8 @@ __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, in
     rng_normal_pair(rng, &nx, &ny);
     if (!P.jitter) nx = ny = 0;
     float sx = (float)px + 0.33f * nx, sy = (float)py + 0.33f * ny;
-    float u = (2 * sx - (float)P.width) / (float)P.height;
-    float v = (2 * sy - (float)P.height) / (float)P.height;
+    float u = pt_div(2 * sx - (float)P.width, (float)P.height);
+    float v = pt_div(2 * sy - (float)P.height, (float)P.height);
     f3 o, d;
     camera_ray(P, u, v, &o, &d);
     Tally n = {};
@@ -1538,7 +1613,7 @@ __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, in
     for (;;) {
         walk_slice<false, WIDE>(P, o, d, t_init, -1.0f, stack, wk, n);
         bool finished = wk.ref == kDone && wk.pleaf == 0;
-        if (finished && inside && t_init > 0.0f && wk.h.face >= 0 && wk.h.t2 <= wk.h.t * kNearHi) {
+        if (!PT_FAST && finished && inside && t_init > 0.0f && wk.h.face >= 0 && wk.h.t2 <= wk.h.t * kNearHi) {
             t_init = -t_init;
             walk_reset(P.root, -t_init, wk);
             finished = false;
@@ -1554,6 +1629,7 @@ __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, in
     }
 }
 
+#if !PT_FAST
 // img[i] *= scale: a rank's running mean weighted by its share of the samples, before the sum-reduce (pt_group_render)
 __global__ void __launch_bounds__(256) scale_kernel(float *__restrict__ img, size_t n, float scale) {
     size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
@@ -1567,5 +1643,7 @@ __global__ void rng_stream_kernel(const uint32_t *jump, uint32_t seed_lo, uint32
     rng_init(rng, jump, seed_lo, seed_hi, subsequence);
     for (int i = 0; i < count; i++) out[i] = rng_next(rng);
 }
+#endif // !PT_FAST
 
+} // namespace PT_ARITH_NS
 } // namespace ptc

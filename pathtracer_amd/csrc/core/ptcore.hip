@@ -16,10 +16,12 @@
 #include <vector>
 
 #include "kernel.h"
+#include "launch.h"
 #include "layout.h"
 #include "ptcore.h"
 
 using namespace ptc;
+using namespace ptc::exact; // this file holds the exact-arithmetic kernels; kernels_fast.hip the tolerance ones
 
 namespace {
 
@@ -233,6 +235,9 @@ struct pt_context {
     int stack_need = 0;  // traversal stack entries a walk of the binary tree can need (height - 1)
     int stack_need4 = 0; // ... of the four-wide tree (with its binary fallback): picks the 32/48/64-entry kernel
     int walk_tree = 0;  // 0 = not chosen yet for this tree, 2 = binary, 4 = four-wide
+    int tree_at_upload = 0; // what pt_bvh_upload decided without timing (PT_TREE, stack bound): 0 = open
+    bool coincident = false; // faces on the same three points: exact arithmetic keeps to the binary tree
+    const KernelLaunchers *kern = &launchers_exact(); // arithmetic variant of the kernels (pt_set_arithmetic)
     KernelParams P{};
 };
 
@@ -251,6 +256,13 @@ int ready(pt_context *ctx) {
     if (!ctx->have_lst) return fail("pt_lst_upload has not been called");
     if (!ctx->have_cfg) return fail("pt_configure has not been called");
     return 0;
+}
+
+// The tree form known without timing: what the upload fixed, and for exact arithmetic the binary tree when faces
+// coincide (it keeps the reference's tie order; tolerance arithmetic keeps no tie order). 0 = time both.
+int initial_tree(const pt_context *ctx) {
+    if (ctx->tree_at_upload) return ctx->tree_at_upload;
+    return (ctx->coincident && ctx->kern == &launchers_exact()) ? 2 : 0;
 }
 
 void set_launch(KernelParams &P, int seed, int prev, int cur, int jitter) {
@@ -323,19 +335,6 @@ void launch_tile_rng(KernelParams &P, const TileScratch &ts, uint32_t ntx, uint3
                        (uint32_t)ts.rows);
 }
 
-template <bool COUNT, int ROWS, bool WIDE>
-void launch_render_as(const pt_context *ctx, const KernelParams &P, dim3 grid, float *img, unsigned long long *counters, hipStream_t st) {
-    const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
-    if (need <= 32)
-        hipLaunchKernelGGL((render_kernel<COUNT, 32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P, img, counters);
-    else if (need <= 40)
-        hipLaunchKernelGGL((render_kernel<COUNT, 40, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P, img, counters);
-    else if (need <= 48)
-        hipLaunchKernelGGL((render_kernel<COUNT, 48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P, img, counters);
-    else
-        hipLaunchKernelGGL((render_kernel<COUNT, 64, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P, img, counters);
-}
-
 template <bool COUNT>
 void launch_render(const pt_context *ctx, KernelParams &P, const TileScratch &ts, bool wide, float *img, unsigned long long *counters,
                    hipStream_t st) {
@@ -345,21 +344,7 @@ void launch_render(const pt_context *ctx, KernelParams &P, const TileScratch &ts
     P.tile_order = (ts.order_valid && g_lpt) ? ts.order : nullptr;
     P.tile_cost = g_lpt ? ts.cost : nullptr;
     launch_tile_rng(P, ts, ntx, nty, st);
-    if (ts.rows == 16) {
-        if (wide) launch_render_as<COUNT, 16, true>(ctx, P, grid, img, counters, st);
-        else launch_render_as<COUNT, 16, false>(ctx, P, grid, img, counters, st);
-    } else {
-        if (wide) launch_render_as<COUNT, 8, true>(ctx, P, grid, img, counters, st);
-        else launch_render_as<COUNT, 8, false>(ctx, P, grid, img, counters, st);
-    }
-}
-
-template <int ROWS, bool WIDE> void launch_probe_as(const pt_context *ctx, const KernelParams &P, dim3 grid, hipStream_t st) {
-    const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
-    if (need <= 32) hipLaunchKernelGGL((cost_probe_kernel<32, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P);
-    else if (need <= 40) hipLaunchKernelGGL((cost_probe_kernel<40, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P);
-    else if (need <= 48) hipLaunchKernelGGL((cost_probe_kernel<48, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P);
-    else hipLaunchKernelGGL((cost_probe_kernel<64, ROWS, WIDE>), grid, dim3(kBlock), 0, st, P);
+    ctx->kern->render(COUNT, wide ? ctx->stack_need4 : ctx->stack_need, ts.rows, wide, grid, P, img, counters, st);
 }
 
 // Short launch without an image: records the tile costs (see pt_render_batch_into).
@@ -370,13 +355,7 @@ void launch_probe(const pt_context *ctx, KernelParams &P, const TileScratch &ts,
     P.tile_order = nullptr;
     P.tile_cost = ts.cost;
     launch_tile_rng(P, ts, ntx, nty, st);
-    if (ts.rows == 16) {
-        if (wide) launch_probe_as<16, true>(ctx, P, grid, st);
-        else launch_probe_as<16, false>(ctx, P, grid, st);
-    } else {
-        if (wide) launch_probe_as<8, true>(ctx, P, grid, st);
-        else launch_probe_as<8, false>(ctx, P, grid, st);
-    }
+    ctx->kern->probe(wide ? ctx->stack_need4 : ctx->stack_need, ts.rows, wide, grid, P, st);
 }
 
 // The context's own tile scratch (allocated by pt_configure), and what a launch left in it.
@@ -439,6 +418,8 @@ int create_resources(pt_context *ctx) {
     unsigned long long zeros[32] = {0};
     if (ctx->counters.upload(zeros, 32)) return 1;
     ctx->P.jump = ctx->jump.ptr;
+    if (const char *e = getenv("PT_ARITHMETIC")) // default of new contexts (the CLI has no flag for it: the reference's flag surface is kept)
+        if (strcmp(e, "fast") == 0) ctx->kern = &launchers_fast();
     return 0;
 }
 } // namespace
@@ -606,10 +587,11 @@ extern "C" int pt_bvh_upload(pt_context *ctx, const pt_bvh_node *nodes, uint32_t
     ctx->P.root4 = baked.root4;
     ctx->stack_need = stack_need;
     ctx->stack_need4 = stack_need4;
-    ctx->walk_tree = 0;
-    if (const char *e = getenv("PT_TREE")) ctx->walk_tree = strcmp(e, "wide") == 0 ? 4 : (strcmp(e, "binary") == 0 ? 2 : 0);
-    if (stack_need4 > 64) ctx->walk_tree = 2; // the folded tree could overflow the largest stack: binary only
-    if (ctx->walk_tree == 0 && has_coincident_faces(ctx->h_shade)) ctx->walk_tree = 2; // keeps the reference's tie order
+    ctx->tree_at_upload = 0;
+    if (const char *e = getenv("PT_TREE")) ctx->tree_at_upload = strcmp(e, "wide") == 0 ? 4 : (strcmp(e, "binary") == 0 ? 2 : 0);
+    if (stack_need4 > 64) ctx->tree_at_upload = 2; // the folded tree could overflow the largest stack: binary only
+    ctx->coincident = ctx->tree_at_upload == 0 && has_coincident_faces(ctx->h_shade);
+    ctx->walk_tree = initial_tree(ctx);
     ctx->order_valid = false;
     if (ctx->tris.upload(baked.tris.data(), baked.tris.size())) return 1;
     ctx->P.nodes = ctx->nodes.ptr;
@@ -720,10 +702,16 @@ extern "C" int pt_configure(pt_context *ctx, const pt_render_config *cfg) {
         ctx->tile_rows = rows;
     }
     size_t tiles = (size_t)((P.width + 7) / 8) * (size_t)((P.height + 7) / 8);
-    if (ctx->tile_cost.count != tiles) {
+    if (ctx->tile_rng.count != tiles * 8 || ctx->tile_cost.count != tiles || ctx->tile_key.count != tiles || ctx->tile_order.count != tiles) {
         ctx->order_valid = false;
-        if (ctx->tile_rng.resize(tiles * 8) || ctx->tile_cost.resize(tiles) || ctx->tile_key.resize(tiles) || ctx->tile_order.resize(tiles))
+        if (ctx->tile_rng.resize(tiles * 8) || ctx->tile_cost.resize(tiles) || ctx->tile_key.resize(tiles) || ctx->tile_order.resize(tiles)) {
+            // all four or none: a later call with the same size must allocate again, not trust a null pointer
+            ctx->tile_rng.release();
+            ctx->tile_cost.release();
+            ctx->tile_key.release();
+            ctx->tile_order.release();
             return 1;
+        }
     }
     ctx->have_cfg = true;
     return 0;
@@ -902,16 +890,6 @@ extern "C" int pt_rng_stream(pt_context *ctx, uint64_t seed, uint64_t subsequenc
     return 0;
 }
 
-namespace {
-template <bool WIDE> void launch_primary(pt_context *ctx, int32_t *d_faces, float *d_dist, unsigned long long *d_redone) {
-    const int need = WIDE ? ctx->stack_need4 : ctx->stack_need;
-    dim3 grid = grid_of(ctx), block(kBlock);
-    if (need <= 32) hipLaunchKernelGGL((primary_hits_kernel<32, WIDE>), grid, block, 0, ctx->stream, ctx->P, d_faces, d_dist, d_redone);
-    else if (need <= 48) hipLaunchKernelGGL((primary_hits_kernel<48, WIDE>), grid, block, 0, ctx->stream, ctx->P, d_faces, d_dist, d_redone);
-    else hipLaunchKernelGGL((primary_hits_kernel<64, WIDE>), grid, block, 0, ctx->stream, ctx->P, d_faces, d_dist, d_redone);
-}
-} // namespace
-
 extern "C" int pt_primary_hits(pt_context *ctx, int seed, int jitter, int tree, int32_t *host_face_ids, float *host_distances,
                                uint64_t *redone_walks) {
     if (ready(ctx)) return 1;
@@ -931,8 +909,8 @@ extern "C" int pt_primary_hits(pt_context *ctx, int seed, int jitter, int tree, 
     set_launch(ctx->P, seed, 0, 1, jitter);
     e = hipMemsetAsync(ctx->counters.ptr, 0, sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
-        if (tree == 4) launch_primary<true>(ctx, d_faces, d_dist, ctx->counters.ptr);
-        else launch_primary<false>(ctx, d_faces, d_dist, ctx->counters.ptr);
+        ctx->kern->primary(tree == 4 ? ctx->stack_need4 : ctx->stack_need, tree == 4, grid_of(ctx), ctx->P, d_faces, d_dist,
+                           ctx->counters.ptr, ctx->stream);
         e = hipStreamSynchronize(ctx->stream);
     }
     unsigned long long redone = 0;
@@ -1075,6 +1053,32 @@ extern "C" pt_context *pt_group_context(pt_group *g, int rank) {
     return (g && rank >= 0 && (size_t)rank < g->ctx.size()) ? g->ctx[(size_t)rank] : nullptr;
 }
 
+// The batch plan of a sharded render, as a pure function of its arguments (no device, no group): batch b of the
+// reference's loop (main.cu:101-102: cur = min(samples_every_update, remaining)) runs on rank b mod ranks with
+// seed + b, and continues that rank's running mean (previous_samples = what the rank has rendered so far).
+// weights[r] = rank r's share of the samples; they sum to 1 (in double, before the rounding to float), and a rank
+// without a batch has weight 0 (its zero-filled accumulator then adds nothing to the reduce).
+extern "C" int pt_group_plan(int seed, int samples, int samples_every_update, int ranks, pt_group_batch *batches, int capacity,
+                             float *weights) {
+    if (samples <= 0 || samples_every_update <= 0 || ranks <= 0) {
+        fail("pt_group_plan: bad arguments (samples %d, samples_every_update %d, ranks %d)", samples, samples_every_update, ranks);
+        return -1;
+    }
+    std::vector<int> local((size_t)ranks, 0);
+    int done = 0, b = 0;
+    while (done < samples) {
+        const int cur = samples_every_update < samples - done ? samples_every_update : samples - done;
+        const int r = b % ranks;
+        if (batches && b < capacity) batches[b] = pt_group_batch{b, r, (int)((int64_t)seed + b), local[(size_t)r], cur};
+        local[(size_t)r] += cur;
+        done += cur;
+        b++;
+    }
+    if (weights)
+        for (int r = 0; r < ranks; r++) weights[r] = (float)((double)local[(size_t)r] / (double)samples);
+    return b;
+}
+
 extern "C" int pt_group_render(pt_group *g, int seed, int samples, int samples_every_update) {
     if (!g || g->ctx.empty()) return fail("pt_group_render: null group");
     if (samples <= 0 || samples_every_update <= 0) return fail("pt_group_render: bad sample counts (%d, %d)", samples, samples_every_update);
@@ -1083,44 +1087,92 @@ extern "C" int pt_group_render(pt_group *g, int seed, int samples, int samples_e
     for (pt_context *c : g->ctx) {
         if (ready(c)) return 1;
         if (c->P.width != P0.width || c->P.height != P0.height) return fail("pt_group_render: the contexts are configured for different image sizes");
-        HIP_TRY(hipMemsetAsync(c->image.ptr, 0, c->image.bytes(), c->stream));
+    }
+    const int n_batches = pt_group_plan(seed, samples, samples_every_update, n, nullptr, 0, nullptr);
+    if (n_batches < 0) return 1;
+    std::vector<pt_group_batch> plan((size_t)n_batches);
+    std::vector<float> weight((size_t)n);
+    (void)pt_group_plan(seed, samples, samples_every_update, n, plan.data(), n_batches, weight.data());
+
+    // From the first asynchronous call on, a failure must not return while other ranks' streams still carry work
+    // into their accumulators, and must not leave an RCCL group open: every exit goes through `unwind`.
+    bool in_group = false;
+    auto unwind = [&](int rc) {
+        char keep[sizeof(g_error)];
+        memcpy(keep, g_error, sizeof(keep)); // the first failure's message survives the clean-up calls
+        if (in_group) (void)g_rccl.GroupEnd();
+        for (pt_context *c : g->ctx)
+            if (hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream);
+        (void)hipSetDevice(g->ctx[0]->device);
+        if (rc) memcpy(g_error, keep, sizeof(keep));
+        return rc;
+    };
+#define GROUP_HIP(expr)                                                                                      \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return unwind(fail("HIP error: %s (%s)", hipGetErrorString(e_), #expr));        \
+    } while (0)
+#define GROUP_RCCL(expr)                                                                                     \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if (r_ != ncclSuccess) return unwind(fail("RCCL error: %s (%s)", g_rccl.GetErrorString(r_), #expr));  \
+    } while (0)
+
+    for (pt_context *c : g->ctx) {
+        GROUP_HIP(hipSetDevice(c->device));
+        GROUP_HIP(hipMemsetAsync(c->image.ptr, 0, c->image.bytes(), c->stream));
     }
     // the reference's batch loop (main.cu:101-133), batch b on rank b mod n: all launches are asynchronous on
-    // their context's stream, so the GPUs render side by side
-    std::vector<int> local((size_t)n, 0);
-    int done = 0, b = 0;
-    while (done < samples) {
-        const int cur = samples_every_update < samples - done ? samples_every_update : samples - done;
-        pt_context *c = g->ctx[(size_t)(b % n)];
-        if (pt_render_batch_into(c, c->image.ptr, nullptr, seed + b, local[(size_t)(b % n)], cur)) return 1;
-        local[(size_t)(b % n)] += cur;
-        done += cur;
-        b++;
+    // their context's stream, so the GPUs render side by side (the first launch of each context blocks the host
+    // for about 10 ms while it times the two forms of the tree: n x 10 ms at the start of the first render)
+    for (const pt_group_batch &b : plan) {
+        pt_context *c = g->ctx[(size_t)b.rank];
+        if (pt_render_batch_into(c, c->image.ptr, nullptr, b.seed, b.previous_samples, b.current_samples)) return unwind(1);
     }
     // weight every rank's mean by its share of the samples, then ONE sum-reduce to rank 0
     const size_t count = g->ctx[0]->image.count;
     for (int r = 0; r < n; r++) {
         pt_context *c = g->ctx[(size_t)r];
-        HIP_TRY(hipSetDevice(c->device));
-        const float scale = (float)((double)local[(size_t)r] / (double)samples);
-        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->image.ptr, count, scale);
-        HIP_TRY(hipGetLastError());
+        GROUP_HIP(hipSetDevice(c->device));
+        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->image.ptr, count, weight[(size_t)r]);
+        GROUP_HIP(hipGetLastError());
     }
-    RCCL_TRY(g_rccl.GroupStart());
+    GROUP_RCCL(g_rccl.GroupStart());
+    in_group = true;
     for (int r = 0; r < n; r++) {
         pt_context *c = g->ctx[(size_t)r];
-        HIP_TRY(hipSetDevice(c->device));
-        RCCL_TRY(g_rccl.Reduce(c->image.ptr, c->image.ptr, count, ncclFloat, ncclSum, 0, g->comm[(size_t)r], c->stream));
+        GROUP_HIP(hipSetDevice(c->device));
+        GROUP_RCCL(g_rccl.Reduce(c->image.ptr, c->image.ptr, count, ncclFloat, ncclSum, 0, g->comm[(size_t)r], c->stream));
     }
-    RCCL_TRY(g_rccl.GroupEnd());
+    in_group = false;
+    GROUP_RCCL(g_rccl.GroupEnd());
     for (pt_context *c : g->ctx) {
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        GROUP_HIP(hipSetDevice(c->device));
+        GROUP_HIP(hipStreamSynchronize(c->stream));
     }
+    (void)hipSetDevice(g->ctx[0]->device);
+#undef GROUP_HIP
+#undef GROUP_RCCL
     return 0;
 }
 
 extern "C" int pt_walk_tree(pt_context *ctx) { return ctx ? ctx->walk_tree : 0; }
+
+extern "C" int pt_set_arithmetic(pt_context *ctx, int arithmetic) {
+    if (!ctx) return fail("null context");
+    if (arithmetic != PT_ARITHMETIC_EXACT && arithmetic != PT_ARITHMETIC_FAST) return fail("pt_set_arithmetic: unknown arithmetic %d", arithmetic);
+    const KernelLaunchers *k = arithmetic == PT_ARITHMETIC_FAST ? &launchers_fast() : &launchers_exact();
+    if (k == ctx->kern) return 0;
+    if (bind(ctx)) return 1;
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // launches of the other variant in flight keep their tile-cost writes to themselves
+    ctx->kern = k;
+    ctx->walk_tree = initial_tree(ctx); // which tree is faster is timed per variant
+    ctx->order_valid = false;
+    ctx->epoch++; // the static scratch's tile order belonged to the other variant's costs
+    return 0;
+}
+
+extern "C" int pt_arithmetic(pt_context *ctx) { return (ctx && ctx->kern == &launchers_fast()) ? PT_ARITHMETIC_FAST : PT_ARITHMETIC_EXACT; }
 
 extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
     if (!ctx) return 0;

@@ -99,9 +99,9 @@ def algorithmic_flops(c, tree, table):
         return None, None
     per = table["flop_per_lane"]
     node = per["wide_step"] if tree == 4 else per["binary_step"]
-    leaf_pairs = c["leaf_tests"] if "leaf_tests" in c else c["tri_tests"] / 1.65
-    parts = {"node_steps": node * c["inner_visits"], "leaf_tests": per["leaf_pair"] * leaf_pairs,
-             "vertex_handler": per["vertex_handler"] * c["handler_calls"], "camera_rays": per["start_sample"] * c["samples"]}
+    parts = {"node_steps": node * c["inner_visits"], "leaf_tests": per["leaf_pair"] * c["leaf_tests"],
+             "vertex_handler": per["vertex_handler"] * c["handler_calls"] + per["brdf_eval_pair"] * c["bounces"],
+             "camera_rays": per["start_sample"] * c["samples"], "shadow_results": per["shadow_result"] * c["shadow_results"]}
     return sum(parts.values()), parts
 
 

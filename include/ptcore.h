@@ -63,6 +63,8 @@ const char *pt_last_error(void);
 /* Binds a context to HIP device `device` (replaces the implicit device 0 and
  * default stream of src/main.cu). Builds the XORWOW 2^67 jump tables. */
 int pt_create(int device, pt_context **out);
+/* HIP devices visible to this process (0 without a GPU or a driver; never fails). */
+int pt_device_count(void);
 void pt_destroy(pt_context *ctx);
 
 /* d_scene.device_from_host(h_scene) — src/main.cu:74, src/scene.cu:974-990,

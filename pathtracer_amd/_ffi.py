@@ -89,6 +89,8 @@ class CoreCounters(C.Structure):  # pt_counters (include/ptcore.h)
                                  for i, r in enumerate(self.REGIONS)}
         d["wave_iterations"] = {r: int(self.region_iters[i]) for i, r in enumerate(self.REGIONS)}
         d["redone_walks"] = int(self.redone_walks)
+        # per-lane executions of the regions (sum of active lanes over the waves' passes)
+        d["leaf_tests"], d["handler_calls"], d["shadow_results"] = (int(self.region_lanes[2]), int(self.region_lanes[3]), int(self.region_lanes[4]))
         if self.region_iters[1]:
             tot = 64.0 * self.region_iters[1]
             d["node_step_lanes"] = {"stepping": round(self.region_lanes[1] / tot, 4),

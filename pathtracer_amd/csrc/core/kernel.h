@@ -51,6 +51,13 @@ namespace ptc {
 #ifndef PT_FAST
 #define PT_FAST 0 /* 1: tolerance arithmetic (contraction on, hardware reciprocal / root, no tie bookkeeping) */
 #endif
+// tools/isa_flops.py builds this file with -DPT_MARK_REGIONS -S and counts the fp32 operations between the marks
+// (comment lines in the ISA; the product build has none)
+#ifdef PT_MARK_REGIONS
+#define PT_MARK(text) asm volatile("; PT_MARK " text)
+#else
+#define PT_MARK(text)
+#endif
 #ifndef PT_BLOCK
 #define PT_BLOCK 64 /* threads per workgroup: one wave64 = one 8x8 pixel tile */
 #endif
@@ -632,6 +639,7 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
                 region_tick<COUNT>(n, kRegInner);
                 uint32_t next;
                 if (WIDE && !exact) {
+                    PT_MARK("wide_step begin");
                     // four-wide node (layout.h): four slab tests, nearest child next, the other hits
                     // pushed farthest first
                     const float4 *np = (const float4 *)(P.nodes4 + w.ref);
@@ -696,7 +704,9 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
                         }
                         w.sp += h3 + h2 + h1;
                     }
+                    PT_MARK("wide_step end");
                 } else {
+                    PT_MARK("binary_step begin");
                     // the reference's binary tree; with an infinite reciprocal (a zero direction component) its
                     // exact select-form test, where 0 * inf = NaN decides as in intersect_aabb
                     const float4 *np = (const float4 *)(P.nodes + w.ref);
@@ -729,6 +739,7 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
                             w.sp++;
                         }
                     }
+                    PT_MARK("binary_step end");
                 }
                 if (next > kDone && w.pleaf == 0) { // a leaf and room to park it: keep descending
                     w.pleaf = next;
@@ -746,7 +757,9 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
             if (__builtin_amdgcn_ballot_w64(has) == 0) break;
             if (has) {
                 region_tick<COUNT>(n, kRegLeaf);
+                PT_MARK("leaf_pair begin");
                 test_leaf<COUNT>(P, w.pleaf, o, d, t_stop, w.h, n);
+                PT_MARK("leaf_pair end");
                 w.pleaf = 0;
                 if (w.h.early) {
                     w.ref = kDone;
@@ -1483,7 +1496,9 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         if (need_camera) {
             int px, py;
             pool_pixel<ROWS>(tx, ty, (uint32_t)q, &px, &py);
+            PT_MARK("start_sample begin");
             start_sample<COUNT>(P, px, py, s, n);
+            PT_MARK("start_sample end");
             need_camera = false;
         }
 
@@ -1510,7 +1525,9 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         if (finished && s.mode == kModeNee) { // shadow results are handled on the spot
             unsigned long long tn0 = stamp<COUNT>();
             region_tick<COUNT>(n, kRegNee);
+            PT_MARK("shadow_result begin");
             shadow_result<COUNT>(wk.h, s, n);
+            PT_MARK("shadow_result end");
             walking = false;
             region_time<COUNT>(n, kRegNee, tn0, stamp<COUNT>());
             continue;
@@ -1529,7 +1546,9 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         if (hit.face < 0) hit.t = kNoHit;
 
         // ---- main-ray result: one handler per path vertex ----
+        PT_MARK("vertex_handler begin");
         const bool end_path = vertex_handler<COUNT>(P, hit, s, n);
+        PT_MARK("vertex_handler end");
         region_time<COUNT>(n, kRegMain, tsh0, stamp<COUNT>());
         if (end_path) {
             total = total + s.light;

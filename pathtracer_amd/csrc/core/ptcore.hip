@@ -441,6 +441,11 @@ extern "C" int pt_create(int device, pt_context **out) {
     return 0;
 }
 
+extern "C" int pt_device_count(void) {
+    int ndev = 0;
+    return hipGetDeviceCount(&ndev) == hipSuccess ? ndev : 0;
+}
+
 extern "C" void pt_destroy(pt_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

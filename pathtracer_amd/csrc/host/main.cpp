@@ -93,6 +93,13 @@ int main(int argc, char *argv[]) {
     for (int i = 1; i + 1 < argc; i++)
         if (strcmp(argv[i], "--gpus") == 0) gpus = atoi(argv[i + 1]);
     if (gpus > 0) {
+        const int present = pt_device_count();
+        if (device < 0 || device + gpus > present) {
+            fprintf(stderr, "--gpus %d: this node has %d HIP device%s and PT_DEVICE (the first one to use) is %d; the ranks need devices %d..%d\n",
+                    gpus, present, present == 1 ? "" : "s", device, device, device + gpus - 1);
+            pth_log(1, "--gpus %d needs devices %d..%d, %d present\n", gpus, device, device + gpus - 1, present);
+            return EXIT_FAILURE;
+        }
         std::vector<int> devices;
         for (int i = 0; i < gpus; i++) devices.push_back(device + i);
         pt_group *group = nullptr;

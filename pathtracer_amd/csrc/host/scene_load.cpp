@@ -392,7 +392,7 @@ struct Builder {
             f.material = (uint32_t)material;
             f.vertexCount = 3;
             for (int k = 0; k < 3; k++) {
-                if (indices[i + k] >= vert_count) fail("index past the primitive's vertex count");
+                if (!flat && indices[i + k] >= vert_count) fail("index past the primitive's vertex count"); // (flat: checked while un-sharing)
                 f.vertices[k] = first_vertex + indices[i + k];
             }
             f.shading = PT_BARY_SHADING;
@@ -400,6 +400,10 @@ struct Builder {
                 pt_vec3 A = scene.vertices[f.vertices[0]].position, B = scene.vertices[f.vertices[1]].position;
                 pt_vec3 C = scene.vertices[f.vertices[2]].position;
                 pt_vec3 n = normalized(cross(sub(B, A), sub(C, A)));
+                // A zero-area face has no normal (0/0). No ray can hit it (Moeller-Trumbore rejects |det| < 1e-12,
+                // intersect.cu:56), so the value is never shaded; it gets +z so that nothing non-finite enters the
+                // tangent generator or the device records. The face itself is kept: face indices are identities.
+                if (!(std::isfinite(n.x) && std::isfinite(n.y) && std::isfinite(n.z))) n = v3(0, 0, 1);
                 for (int k = 0; k < 3; k++) scene.vertices[f.vertices[k]].normal = n;
             }
             scene.faces.push_back(f);

@@ -40,3 +40,35 @@ def test_two_ranks_render_and_combine_on_the_gpu(tmp_path):
     assert err <= 2e-6 * scale, (err, scale)  # same samples; flat weighted sum against the running mean
     assert np.abs(combined - single).mean() / np.abs(single).mean() <= 1e-6
     assert not np.array_equal(combined, np.zeros_like(combined)) and single.mean() > 0.1
+
+
+def test_bench_loop_two_ranks_equals_one_rank(tmp_path):
+    """bench.py's OWN loop (plan_job -> plan_batches -> render_local -> combine) with two ranks on the box's one GPU
+    (gloo; the driver's N > 1 runs use RCCL) against the same command with one rank: the same fixed job (3 batches
+    of 5 spp: a ragged 2 + 1 split), the same image to fp32 summation order, value = the whole job's samples / time."""
+    import json
+    if core.CONTEXTS_CREATED:
+        pytest.skip("GPU already initialised in this process; run this file first or alone")
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    bench = os.path.join(_ffi.REPO_ROOT, "bench.py")
+    common = ["--config", "c1", "--res", "160", "--spp", "5", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-tolerance"]
+    lines = {}
+    for n in (1, 2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        img = str(tmp_path / f"bench{n}.npy")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), bench, "--gpus", str(n), "--backend", "gloo", "--one-gpu", "--dump-image", img] + common
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=170, env=env)
+        assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+        lines[n] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    one, two = np.load(str(tmp_path / "bench1.npy")), np.load(str(tmp_path / "bench2.npy"))
+    assert one.shape == two.shape == (160, 160, 3) and np.isfinite(one).all() and one.mean() > 0
+    assert np.abs(two.astype(np.float64) - one).max() <= 2e-6 * np.abs(one).max()
+    for n in (1, 2):
+        ln = lines[n]
+        assert ln["scaling"] == "strong" and ln["n_gpus"] == n and ln["steps"] == 3
+        assert ln["config"]["spp_total"] == 15 and ln["config"]["batches"] == 3 and ln["config"]["spp_per_batch"] == 5
+        assert abs(ln["value"] - 160 * 160 * 15 / ln["elapsed_s"] / 1e6) <= 1e-2 * ln["value"]
+    assert lines[1]["config"]["batches_on_rank0"] == 3 and lines[2]["config"]["batches_on_rank0"] == 2

@@ -54,3 +54,9 @@ def test_cli_renders_the_oracle_image(scene_dir, tmp_path):
     log2 = open(os.path.join(out2, "log.txt")).read()
     assert "on 1 GPUs" in log2 and "Rendered 10 out of 10 S/px" in log2
     assert np.array_equal(host.load_png(os.path.join(out2, "render.png")), png)
+
+    # --gpus N beyond the devices of the node: refused with a message that names both numbers, before any upload
+    out3 = str(tmp_path / "out_too_many")
+    res = subprocess.run([a if a != out else out3 for a in argv] + ["--gpus", "64"], capture_output=True, text=True, timeout=110)
+    assert res.returncode != 0 and "--gpus 64" in res.stderr and "HIP device" in res.stderr and "0..63" in res.stderr
+    assert not os.path.exists(os.path.join(out3, "render.png"))

@@ -6,7 +6,11 @@ with the half vector on the normal, reference arithmetic, DESIGN.md section 5 - 
 
   C2  many_lights STAND-IN (the reference's .bin does not ship) 1024x1024, one batch of 50 spp
   C3  the reference's dragon.gltf (golden arrays)               1024x1024, one batch of 64 spp
-  C4  the reference's glass_mirror.gltf + rose-garden env       1024x1024, one batch of 50 spp
+  C4  the reference's glass_mirror.gltf + rose-garden env       1024x1024, one batch of 50 spp; the env map is the
+      reference's sunny_rose_garden_1k.hdr point-sampled 4x DOWN to 256x128 (a derived fixture: the real texels at a
+      quarter of the resolution), so a second case runs the same scene under a PROCEDURAL map at the full 1024x512
+      (that the loader hands the real file's 1024x512 texels to the kernel unchanged is pinned on the CPU, against the
+      reference's own stb_image: tests/test_reference_pins.py)
   C5  synthetic 10 M-triangle grid                              4096x4096, 4 spp (one GPU's share of a batch)
   soak: 20 random (scene, size, seed, split, tree, tile shape) cases with a fixed generator seed
 Oracle time on the GPU box's 16 threads: about 6 + 5 + 4 + 25 s.
@@ -61,6 +65,16 @@ def test_c3_dragon_full_size(monkeypatch):
 def test_c4_glass_mirror_env_full_size(monkeypatch):
     b = util.golden_scene("glass_mirror", env=True)
     _both_trees(b, 1024, 1024, 42, 50, 50, clear=(1.0, 1.0, 1.0), monkeypatch=monkeypatch, label="C4 glass_mirror.gltf + env")
+
+
+def test_c4_glass_mirror_full_resolution_env(monkeypatch):
+    """Config 4 at the environment map's real size: 1024x512 float texels (8 MB) through pt_scene_upload, bilinear
+    filter with mirrored repeat, 1024x1024 launch, both trees, against the oracle (reference: scene.cu:928-936,
+    mathops.h:712-720)."""
+    b = util.golden_scene("glass_mirror", env="sky1k")
+    px, t = b.scene.texture(0)
+    assert (t.width, t.height, t.isFloat, t.wrapS, t.wrapT, t.filter) == (1024, 512, 1, 2, 2, 1)
+    _both_trees(b, 1024, 1024, 42, 32, 32, clear=(1.0, 1.0, 1.0), monkeypatch=monkeypatch, label="C4 glass_mirror.gltf + 1024x512 procedural env")
 
 
 def test_c5_grid_10m_triangles_4096(scene_dir, monkeypatch):

@@ -691,3 +691,47 @@ def test_loader_flat_shades_a_primitive_without_normals(scene_dir):
         imgs.append(ob.Oracle(sc, host.BVH(sc), host.LST(sc), 48, 48).render(5, 8, 8))
     assert np.isfinite(imgs[0]).all() and imgs[0].mean() > 0.01
     assert np.abs(imgs[0] - imgs[1]).mean() < 0.05 * imgs[1].mean()  # same picture (normals agree to rounding, paths may fork)
+
+
+def test_flat_shaded_zero_area_face_gets_a_finite_normal(scene_dir):
+    """a NORMAL-less primitive with a degenerate triangle. normalize(cross(0)) is 0/0; the loader keeps the
+    face (indices are identities), gives its three corners +z and finite tangents; every other corner carries its
+    face's normal; the oracle renders the scene finite (the face can never be hit: |det| < 1e-12)."""
+    P = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0.5), (2, 2, 1)], np.float32)
+    idx = np.array([0, 1, 2,  1, 3, 2,  0, 4, 4,  3, 3, 3], np.uint32)  # two real faces, an edge-degenerate one, a point
+    w = scenes.GltfWriter()
+    grey = w.material("GREY", (0.6, 0.6, 0.6, 1))
+    emit = w.material("EMIT", (0, 0, 0, 1), emissive=(1, 1, 1), emissive_strength=5)
+    w.doc.setdefault("extensionsUsed", []).append("KHR_materials_emissive_strength")
+    p = w.primitive(P, np.zeros_like(P), idx, grey, P[:, :2].copy())
+    del p["attributes"]["NORMAL"]
+    w.node("Mesh", mesh=w.mesh("Mesh", [p]))
+    w.node("Light", mesh=w.mesh("Light", [scenes.unit_plane(w, emit)]), translation=(0, 0, 3), rotation=(1, 0, 0, 0))
+    w.node("Camera", camera=w.camera(0.7), translation=(0.5, 0.5, 5))
+    sc = host.Scene.load_gltf(w.write(scene_dir, "flat_degenerate"))
+    v, f = sc.vertices, sc.faces
+    assert len(f) == 4 + 2 and len(v) == 12 + 4
+    n = v["normal"][:12].reshape(4, 3, 3)
+    assert np.isfinite(v["normal"]).all() and np.isfinite(v["tangent"]).all()
+    for k in range(4):
+        assert np.array_equal(n[k, 0], n[k, 1]) and np.array_equal(n[k, 0], n[k, 2])
+    tri = v["position"][:6].reshape(2, 3, 3).astype(np.float64)
+    want = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    want /= np.linalg.norm(want, axis=1, keepdims=True)
+    assert np.abs(n[:2, 0] - want).max() < 1e-6
+    assert np.array_equal(n[2, 0], (0, 0, 1)) and np.array_equal(n[3, 0], (0, 0, 1))
+    img = ob.Oracle(sc, host.BVH(sc), host.LST(sc), 32, 32).render(3, 4, 4)
+    assert np.isfinite(img).all() and img.mean() > 0
+
+
+def test_failed_configure_is_not_followed_by_a_trusting_one():
+    """pt_configure allocates four per-tile arrays; if one allocation fails, a later call with the same size
+    must allocate again rather than find a matching count beside a null pointer. Without a GPU the call fails before
+    that (no context), so what is checked here is the source's shape: the size test covers all four arrays and the
+    failure path releases all four."""
+    src = open(os.path.join(_ffi.REPO_ROOT, "pathtracer_amd", "csrc", "core", "ptcore.hip")).read()
+    body = src[src.index('extern "C" int pt_configure('):src.index('extern "C" int pt_clear_image(')]
+    guard = body[body.index("if (ctx->tile_rng.count"):]
+    for name in ("tile_rng", "tile_cost", "tile_key", "tile_order"):
+        assert f"ctx->{name}.count !=" in guard.split("{")[0], name
+        assert f"ctx->{name}.release();" in guard, name

@@ -101,6 +101,10 @@ def test_loader_output_equals_the_reference_libraries(gref, name, env):
         assert a["materials"]["baseColorTexture"][0] == 0
     if name == "glass_mirror":
         assert len(a["lights"]) == 1 and a["clearTexture"] == 0
+        # config 4's environment map reaches the kernel at its FULL 1024x512 float resolution, linear filter, mirrored
+        # repeat (scene.cu:928-936); the GPU gate's rose_garden_env.npz fixture is these texels point-sampled 4x down
+        (w, h, ch, is_float, wrap_s, wrap_t, filt), texels = a["textures"][0]
+        assert (w, h, ch, is_float, wrap_s, wrap_t, filt) == (1024, 512, 4, 1, 2, 2, 1) and len(texels) * texels.itemsize == 1024 * 512 * 16
 
 
 @pytest.mark.parametrize("name", ["sunny_rose_garden_1k.hdr", "farmland_overcast_1k.hdr"])

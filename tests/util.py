@@ -27,13 +27,22 @@ def golden_scene(name, env=False):
     derived arrays (tests/golden/<name>_scene.npz, made by tests/golden/make_golden.py where the reference is
     mounted), so that the BASELINE configurations on real assets run on the GPU box, which has no reference.
     env=True adds BASELINE config 4's environment map as the clear texture (rose_garden_env.npz: the
-    reference's sunny_rose_garden_1k.hdr decoded and point-sampled down to 256x128), with the sampler state
-    the reference gives an environment map: linear filter, mirrored repeat on both axes (scene.cu:928-936)."""
+    reference's sunny_rose_garden_1k.hdr decoded and point-sampled 4x DOWN to 256x128: the real texels, not the
+    real resolution), with the sampler state the reference gives an environment map: linear filter, mirrored
+    repeat on both axes (scene.cu:928-936). env="sky1k": a procedural map at the real 1024x512 resolution."""
     z = np.load(os.path.join(GOLDEN, f"{name}_scene.npz"))
     cam = {"position": tuple(z["camera"][0:3]), "target": tuple(z["camera"][3:6]), "updir": tuple(z["camera"][6:9]),
            "yfov": float(z["camera"][9])}
     textures, clear = (), -1
-    if env:
+    if env == "sky1k":
+        # an environment map at config 4's FULL resolution (1024x512, the size of sunny_rose_garden_1k.hdr): a procedural
+        # Radiance file written here (no asset copied) and read back through the product's own .hdr decoder
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            px = host.load_hdr(scenes.write_sky_hdr(os.path.join(d, "sky1k.hdr"), 1024, 512))
+        assert px.shape == (512, 1024, 4) and px.dtype == np.float32
+        textures, clear = ({"pixels": px, "wrapS": 2, "wrapT": 2, "filter": 1},), 0
+    elif env:
         rgb = np.load(os.path.join(GOLDEN, "rose_garden_env.npz"))["rgb"]
         px = np.ones(rgb.shape[:2] + (4,), np.float32)
         px[..., :3] = rgb

@@ -3,7 +3,7 @@
 summaries kept under profiles/: per-kernel stats (CSV) and PMC counters of the render kernel (JSON).
 
   python3 tools/summarize_profiles.py stats gpurun_out/prof4/vm_results.db profiles/r01_bench_kernel_stats_v3.csv
-  python3 tools/summarize_profiles.py pmc gpurun_out/pmc4 profiles/r01_pmc_v3_many_lights_50spp.json [algorithmic_bytes]
+  python3 tools/summarize_profiles.py pmc gpurun_out/pmc4 profiles/r01_pmc_v3_many_lights_50spp.json [algorithmic_bytes] [command text]
 """
 import csv
 import glob
@@ -24,9 +24,9 @@ def stats(db, out):
         print(r[0][:60], r[1], round(r[3], 1), "us avg")
 
 
-def pmc(root, out, algorithmic=None):
-    res = {"command": "rocprofv3 --pmc <pass> -- python3 tools/prof_run.py --spp 50 --batches 2 (one run per pass; "
-                      "values of the LAST render_kernel<false,32> dispatch, i.e. the re-ordered launch)", "passes": {}}
+def pmc(root, out, algorithmic=None, command=None):
+    res = {"command": (command or "rocprofv3 --pmc <pass> -- python3 tools/prof_run.py --spp 50 --batches 2") +
+                      " (one run per pass; values of the LAST render_kernel<false, ...> dispatch, i.e. the re-ordered launch)", "passes": {}}
     for d in sorted(glob.glob(os.path.join(root, "*"))):
         db = os.path.join(d, "vm_results.db")
         if not os.path.exists(db):
@@ -42,6 +42,8 @@ def pmc(root, out, algorithmic=None):
             if disp == last:
                 agg[name] = agg.get(name, 0.0) + float(value)
                 agg["_duration_ns"] = dur
+        kn = c.execute("select distinct kernel_name from counters_collection where kernel_name like '%render_kernel<false%'").fetchall()
+        res["kernel"] = kn[-1][0] if kn else None
         res["passes"][os.path.basename(d)] = agg
     P = res["passes"]
     der = {}
@@ -71,6 +73,16 @@ def pmc(root, out, algorithmic=None):
         wc = P["p1"]["SQ_WAVE_CYCLES"]
         der["wave_cycle_shares"] = {"issuing": P["p2"]["SQ_ACTIVE_INST_ANY"] / wc, "waiting_on_memory_or_barrier": P["p2"]["SQ_WAIT_ANY"] / wc,
                                     "issue_stalled": P["p1"]["SQ_WAIT_INST_ANY"] / wc}
+    if "p1" in P and "launch_cycles_per_xcd" in der and "SQ_WAVE_CYCLES" in P["p1"]:
+        der["resident_waves_per_simd"] = P["p1"]["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * der["launch_cycles_per_xcd"])  # counter ticks every 4 cycles
+    if "p4" in P and "TCP_TOTAL_CACHE_ACCESSES_sum" in P["p4"]:
+        der["l1_accesses"] = P["p4"]["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        der["l1_to_l2_read_requests"] = P["p4"]["TCP_TCC_READ_REQ_sum"]
+    if "hbm_traffic_per_launch" in der and "f" in P:
+        der["launch_ms"] = P["f"]["_duration_ns"] / 1e6
+        der["fabric_GBps"] = der["hbm_traffic_per_launch"] / P["f"]["_duration_ns"]
+        if algorithmic:
+            der["traffic_over_algorithmic"] = der["hbm_traffic_per_launch"] / float(algorithmic)
     res["derived"] = der
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
@@ -81,4 +93,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None, sys.argv[5] if len(sys.argv) > 5 else None)

@@ -32,6 +32,16 @@ class NonfiniteDiag(C.Structure):  # orc_nonfinite_diag
         return {n: (list(getattr(self, n)) if hasattr(getattr(self, n), "__len__") else getattr(self, n)) for n, _ in self._fields_}
 
 
+class MarginStats(C.Structure):  # orc_margin_stats
+    _fields_ = [("rays", C.c_uint64), ("leaf_looks", C.c_uint64), ("hits", C.c_uint64),
+                ("entry_behind", C.c_uint64), ("exit_in_front", C.c_uint64),
+                ("max_entry_behind", C.c_double), ("max_exit_in_front", C.c_double),
+                ("culled_by_distance", C.c_uint64), ("max_culled_gap", C.c_double),
+                ("missed_box", C.c_uint64), ("max_rim_of_missed", C.c_double),
+                ("missed_box_inf_rinv", C.c_uint64), ("max_rim_of_missed_finite", C.c_double), ("max_t_of_missed_finite", C.c_double),
+                ("rays_with_two_candidates", C.c_uint64), ("gap_below", C.c_uint64 * 16)]
+
+
 _lib = None
 
 
@@ -56,6 +66,7 @@ def lib():
         L.orc_rng_sequence_jump_matrix.restype = None
         L.orc_primary_hits.argtypes = [C.POINTER(Inputs), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_find_nonfinite.argtypes = [C.POINTER(Inputs), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(NonfiniteDiag)]
+        L.orc_margin_probe.argtypes = [C.POINTER(Inputs), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MarginStats)]
         L.orc_tonemap_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_sample_texture.argtypes = [C.POINTER(_ffi.Texture), C.c_float, C.c_float, C.c_void_p]
         L.orc_sample_texture.restype = None
@@ -116,6 +127,16 @@ class Oracle:
         """Where pixel (px, py) of that batch first turns non-finite (None if it does not)."""
         d = NonfiniteDiag()
         return d.as_dict() if lib().orc_find_nonfinite(C.byref(self.inputs), seed, current_samples, px, py, C.byref(d)) else None
+
+    def margin_probe(self, seed, current_samples, threads=0, rows=None):
+        """orc_margin_probe: how far box and triangle arithmetic disagree along the rays of this render."""
+        m = MarginStats()
+        y0, y1 = rows if rows is not None else (0, self.height)
+        if lib().orc_margin_probe(C.byref(self.inputs), seed, current_samples, y0, y1, threads, C.byref(m)):
+            raise RuntimeError("oracle margin probe failed")
+        d = {n: getattr(m, n) for n, _ in MarginStats._fields_ if n != "gap_below"}
+        d["gap_below"] = list(m.gap_below)
+        return d
 
     def primary_hits(self, seed, jitter=True):
         ids = np.zeros((self.height, self.width), np.int32)

@@ -269,6 +269,7 @@ struct Ctx {
     Rng rng;
     orc_counters n{};
     orc_nonfinite_diag *diag = nullptr; // orc_find_nonfinite only
+    orc_margin_stats *probe = nullptr;  // orc_margin_probe only
     int sample_index = 0;
 };
 
@@ -386,6 +387,49 @@ inline float intersect_aabb(const pt_bvh_node &n, const Ray &ray, V3 r_inv, floa
     return 1e30f;
 }
 
+// orc_margin_probe: the traversal is about to apply the box test of leaf `leaf` against the best distance `best`
+void probe_leaf(Ctx &c, const Ray &ray, V3 r_inv, const pt_bvh_node &leaf, float best, float *t_first, float *t_second) {
+    orc_margin_stats &m = *c.probe;
+    m.leaf_looks++;
+    V3 t1 = (from(leaf.bmin) - ray.o) * r_inv, t2 = (from(leaf.bmax) - ray.o) * r_inv;
+    float tmin = max_comp(vmin(t1, t2)), tmax = min_comp(vmax(t1, t2));
+    const bool geometric = tmax >= tmin && tmax > 0; // the box test but for the distance cull
+    for (uint32_t i = leaf.start; i < leaf.end; i++) {
+        const pt_face &face = c.sc->faces[c.in->indices[i]];
+        float t, u, v;
+        if (!moeller_trumbore(ray, from(c.sc->vertices[face.vertices[0]].position), from(c.sc->vertices[face.vertices[1]].position),
+                              from(c.sc->vertices[face.vertices[2]].position), &t, &u, &v)) continue;
+        if (!(t >= 0 && t < best)) continue;
+        m.hits++;
+        if (t < *t_first) { *t_second = *t_first; *t_first = t; } else if (t < *t_second) *t_second = t;
+        const double td = t > 0 ? (double)t : 1e-30;
+        if (!geometric) {
+            m.missed_box++;
+            double rim = std::min(std::min((double)u, (double)v), 1.0 - ((double)u + (double)v));
+            if (rim > m.max_rim_of_missed) m.max_rim_of_missed = rim;
+            if (std::isinf(r_inv.x) || std::isinf(r_inv.y) || std::isinf(r_inv.z)) {
+                m.missed_box_inf_rinv++;
+            } else {
+                if (rim > m.max_rim_of_missed_finite) m.max_rim_of_missed_finite = rim;
+                if (t > m.max_t_of_missed_finite) m.max_t_of_missed_finite = t;
+            }
+            continue;
+        }
+        if (tmin > t) {
+            m.entry_behind++;
+            m.max_entry_behind = std::max(m.max_entry_behind, ((double)tmin - t) / td);
+        }
+        if (tmax < t) {
+            m.exit_in_front++;
+            m.max_exit_in_front = std::max(m.max_exit_in_front, ((double)t - tmax) / td);
+        }
+        if (!(tmin < best)) {
+            m.culled_by_distance++;
+            m.max_culled_gap = std::max(m.max_culled_gap, ((double)tmin - t) / td);
+        }
+    }
+}
+
 // bvh.cu:239-286
 void intersect(Ctx &c, const Ray &ray, Hit &hit) {
     c.n.rays++;
@@ -395,6 +439,19 @@ void intersect(Ctx &c, const Ray &ray, Hit &hit) {
     const pt_bvh_node *stack[64];
     int depth = 0;
     stack[0] = &nodes[0];
+    float probe_first = 1e30f, probe_second = 1e30f;
+    struct ProbeEnd { // at the end of the walk: the runner-up's gap
+        Ctx &c; float &a, &b;
+        ~ProbeEnd() {
+            if (!c.probe) return;
+            c.probe->rays++;
+            if (b >= 1e30f || !(a > 0)) return;
+            c.probe->rays_with_two_candidates++;
+            double gap = ((double)b - a) / a;
+            for (int k = 0; k < 16; k++)
+                if (gap < std::ldexp(1.0, -(k + 8))) c.probe->gap_below[k]++;
+        }
+    } probe_end{c, probe_first, probe_second};
     while (depth >= 0) {
         const pt_bvh_node *node = stack[depth--];
         while (node) {
@@ -405,6 +462,10 @@ void intersect(Ctx &c, const Ray &ray, Hit &hit) {
                 c.n.inner_visits++;
                 const pt_bvh_node *c1 = &nodes[node->leftChild];
                 const pt_bvh_node *c2 = &nodes[node->rightChild];
+                if (c.probe) {
+                    if (c1->end - c1->start > 0) probe_leaf(c, ray, r_inv, *c1, hit.distance, &probe_first, &probe_second);
+                    if (c2->end - c2->start > 0) probe_leaf(c, ray, r_inv, *c2, hit.distance, &probe_first, &probe_second);
+                }
                 float t1 = intersect_aabb(*c1, ray, r_inv, hit.distance);
                 float t2 = intersect_aabb(*c2, ray, r_inv, hit.distance);
                 if (t2 < t1) {
@@ -795,6 +856,61 @@ extern "C" int orc_find_nonfinite(const orc_inputs *in, int seed, int cur, int p
         (void)integrate_Li(c, camera_ray(in->scene->camera, u, v));
     }
     return out->found;
+}
+
+extern "C" int orc_margin_probe(const orc_inputs *in, int seed, int cur, int y0, int y1, int threads, orc_margin_stats *out) {
+    if (!in || !in->scene || !out || cur <= 0) return 1;
+    int W = in->cfg.resolution_x, H = in->cfg.resolution_y;
+    if (y0 < 0) y0 = 0;
+    if (y1 > H) y1 = H;
+    std::call_once(g_jump_once, build_jump);
+    unsigned n = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    std::atomic<int> next_row{y0};
+    std::vector<orc_margin_stats> per_thread(n);
+    auto work = [&](unsigned id) {
+        orc_margin_stats m;
+        memset(&m, 0, sizeof(m));
+        for (;;) {
+            int y = next_row.fetch_add(1);
+            if (y >= y1) break;
+            for (int x = 0; x < W; x++) {
+                Ctx c;
+                c.in = in;
+                c.sc = in->scene;
+                c.probe = &m;
+                rng_init(c.rng, (uint64_t)(int64_t)seed, (uint64_t)(int64_t)(y * W + x));
+                for (int i = 0; i < cur; i++) { // render_pixel's loop
+                    float sx = (float)x + 0.33f * rng_normal(c.rng);
+                    float sy = (float)y + 0.33f * rng_normal(c.rng);
+                    float u = (2 * sx - (float)W) / (float)H;
+                    float v = (2 * sy - (float)H) / (float)H;
+                    (void)integrate_Li(c, camera_ray(in->scene->camera, u, v));
+                }
+            }
+        }
+        per_thread[id] = m;
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &t : pool) t.join();
+    memset(out, 0, sizeof(*out));
+    for (const orc_margin_stats &m : per_thread) {
+        out->rays += m.rays; out->leaf_looks += m.leaf_looks; out->hits += m.hits;
+        out->entry_behind += m.entry_behind; out->exit_in_front += m.exit_in_front;
+        out->culled_by_distance += m.culled_by_distance; out->missed_box += m.missed_box;
+        out->rays_with_two_candidates += m.rays_with_two_candidates;
+        out->max_entry_behind = std::max(out->max_entry_behind, m.max_entry_behind);
+        out->max_exit_in_front = std::max(out->max_exit_in_front, m.max_exit_in_front);
+        out->max_culled_gap = std::max(out->max_culled_gap, m.max_culled_gap);
+        out->max_rim_of_missed = std::max(out->max_rim_of_missed, m.max_rim_of_missed);
+        out->missed_box_inf_rinv += m.missed_box_inf_rinv;
+        out->max_rim_of_missed_finite = std::max(out->max_rim_of_missed_finite, m.max_rim_of_missed_finite);
+        out->max_t_of_missed_finite = std::max(out->max_t_of_missed_finite, m.max_t_of_missed_finite);
+        for (int k = 0; k < 16; k++) out->gap_below[k] += m.gap_below[k];
+    }
+    return 0;
 }
 
 extern "C" void orc_rng_set_scramble(const uint32_t constants[4]) {

@@ -96,6 +96,36 @@ typedef struct {
 } orc_nonfinite_diag;
 int orc_find_nonfinite(const orc_inputs *in, int seed, int current_samples, int px, int py, orc_nonfinite_diag *out);
 
+/* Measurement behind the margins of the product's speculative walks (kernel.h: kCullSlack, kNearHi, kEdgeBand): how far
+ * the box arithmetic (bvh.cu:222-237) and the triangle arithmetic (intersect.cu:12-81) disagree about ONE ray. The
+ * render of orc_render_rows is repeated with a probe in the traversal: whenever the walk looks at a child that is a
+ * leaf, whatever the box test said, every triangle of that leaf is also intersected, and for each one the ray hits in
+ * front of the best distance so far (a hit the reference accepts if it gets to test it) the leaf box's raw entry and
+ * exit distances are compared with the triangle's t. All gaps are relative to t. */
+typedef struct {
+    uint64_t rays, leaf_looks, hits;
+    /* the box test passes, but the box's entry distance lies BEHIND the triangle's t (or its exit in front of it) */
+    uint64_t entry_behind, exit_in_front;
+    double max_entry_behind, max_exit_in_front;
+    /* the box test culls the leaf against the best distance although the triangle is nearer than it (what kCullSlack is for) */
+    uint64_t culled_by_distance;
+    double max_culled_gap;
+    /* the box test MISSES the leaf (exit before entry, or behind the origin) although the ray hits a triangle in it
+     * (what kEdgeBand is for): how far inside the triangle such a hit can be (smallest barycentric weight) */
+    uint64_t missed_box;
+    double max_rim_of_missed;
+    /* ... of which by rays whose direction has a zero component (infinite reciprocal: 0 * inf = NaN in the box test; the
+     * product walks those on the reference's own tree with its select-form test), and the deepest hit of the OTHERS */
+    uint64_t missed_box_inf_rinv;
+    double max_rim_of_missed_finite;
+    double max_t_of_missed_finite;
+    /* per ray: relative gap between the accepted closest hit and the runner-up among the accepted candidates,
+     * histogram over powers of two: gap_below[k] = rays with gap < 2^-(k+8), k = 0..15 (2^-8 .. 2^-23) */
+    uint64_t rays_with_two_candidates;
+    uint64_t gap_below[16];
+} orc_margin_stats;
+int orc_margin_probe(const orc_inputs *in, int seed, int current_samples, int y0, int y1, int threads, orc_margin_stats *out);
+
 /* write_image's tonemapped 8-bit RGB buffer (src/image.cu:72-99: extended Reinhard on luminance with the white
  * point max(1, max luminance), sRGB gamma, (uint8_t)(255 * c), vertical flip), restated independently of
  * pathtracer_amd/csrc/host/image_io.cpp; out = width * height * 3 bytes. Returns 1 on a non-finite input. */

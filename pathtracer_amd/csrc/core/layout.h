@@ -121,6 +121,11 @@ struct BakedBvh {
     std::vector<GTri> tris;
     uint32_t root = 0; // child reference of the root
     int height = 0;    // nodes on the longest root-to-leaf path
+    // The same binary tree with its bottom levels folded into leaves of up to `fold` triangles (fold_leaves): what
+    // SPECULATIVE walks use, directly (binary form) or folded four-wide (nodes4). Equal to nodes / root when fold <= 2.
+    std::vector<GNode> nodes_fold;
+    uint32_t root_fold = 0;
+    uint32_t fold = 0;
     std::vector<GNode4> nodes4;
     uint32_t root4 = 0;   // child reference of the wide root (a leaf reference when the tree is one leaf)
     int stack4 = 0;       // most stack entries a wide walk can hold at once
@@ -207,12 +212,89 @@ inline std::string bake_bvh(const std::vector<GShade> &shade, const pt_bvh_node 
     return "";
 }
 
-// Folds the baked binary tree into four-wide nodes. Call after bake_bvh.
-inline void bake_bvh4(BakedBvh &b) {
-    b.nodes4.clear();
-    b.root4 = b.root;
-    b.stack4 = 0;
-    if (b.nodes.empty()) return; // single leaf
+// Folds the bottom of the baked binary tree into larger leaves: an inner node whose subtree holds at most max_tris
+// triangles (<= 8, the leaf format's limit) in ONE contiguous run of the triangle array becomes a leaf reference in
+// its parent. The reference builder partitions index ranges in place (bvh.cu:136-192), so every subtree of its
+// trees is such a run; a foreign tree whose subtrees are scattered simply folds nowhere. The reference's leaves
+// hold at most 2 faces (bvh.cu:143): its walk then pays an inner-node visit (two box tests, a 64-byte fetch, a
+// stack operation) to choose between two leaves of one or two triangles each, where testing the four triangles
+// costs about the same arithmetic in half the steps. Only speculative walks use the folded form; the sequential
+// re-walk that settles near-ties follows the reference's own tree (nodes / root), so the reference's visiting order
+// is untouched where it matters. Call after bake_bvh, before bake_bvh4.
+inline void fold_leaves(BakedBvh &b, uint32_t max_tris) {
+    b.nodes_fold.clear();
+    b.root_fold = b.root;
+    b.fold = max_tris;
+    if (max_tris > kMaxLeafTris) max_tris = kMaxLeafTris;
+    if (b.nodes.empty() || max_tris <= 2) {
+        b.nodes_fold = b.nodes;
+        return;
+    }
+    const size_t n = b.nodes.size();
+    std::vector<uint32_t> first(n), count(n);
+    std::vector<char> run(n);
+    auto span = [&](uint32_t ref, uint32_t *f, uint32_t *c, bool *r) {
+        if (ref & kLeafBit) {
+            *f = ref & 0x0FFFFFFFu;
+            *c = ((ref >> 28) & 7u) + 1u;
+            *r = true;
+        } else {
+            *f = first[ref];
+            *c = count[ref];
+            *r = run[ref] != 0;
+        }
+    };
+    for (size_t k = n; k-- > 0;) { // children follow parents
+        uint32_t fl, cl, fr, cr;
+        bool rl, rr;
+        span(b.nodes[k].left, &fl, &cl, &rl);
+        span(b.nodes[k].right, &fr, &cr, &rr);
+        first[k] = fl < fr ? fl : fr;
+        count[k] = cl + cr;
+        run[k] = rl && rr && (fl + cl == fr || fr + cr == fl);
+    }
+    auto folds = [&](uint32_t ref) { return !(ref & kLeafBit) && run[ref] && count[ref] <= max_tris; };
+    if (folds(0)) { // the whole tree is one leaf
+        b.root_fold = leaf_ref(first[0], count[0]);
+        return;
+    }
+    // nodes that survive: reachable from the root without passing a folded node; dense remap in the old order
+    std::vector<uint32_t> remap(n, 0xFFFFFFFFu);
+    std::vector<char> keep(n, 0);
+    keep[0] = 1;
+    for (size_t k = 0; k < n; k++) {
+        if (!keep[k]) continue;
+        const uint32_t c[2] = {b.nodes[k].left, b.nodes[k].right};
+        for (uint32_t ref : c)
+            if (!(ref & kLeafBit) && !folds(ref)) keep[ref] = 1;
+    }
+    uint32_t kept = 0;
+    for (size_t k = 0; k < n; k++)
+        if (keep[k]) remap[k] = kept++;
+    b.nodes_fold.resize(kept);
+    for (size_t k = 0; k < n; k++) {
+        if (!keep[k]) continue;
+        GNode g = b.nodes[k];
+        uint32_t *c[2] = {&g.left, &g.right};
+        for (uint32_t *ref : c) {
+            if (*ref & kLeafBit) continue;
+            *ref = folds(*ref) ? leaf_ref(first[*ref], count[*ref]) : remap[*ref];
+        }
+        b.nodes_fold[remap[k]] = g;
+    }
+    b.root_fold = 0;
+}
+
+// Folds the (leaf-folded) binary tree into four-wide nodes. Call after bake_bvh and fold_leaves.
+inline void bake_bvh4(BakedBvh &bvh) {
+    struct Source { // the binary tree the wide one is made from
+        const std::vector<GNode> &nodes;
+        uint32_t root;
+    } b{bvh.nodes_fold, bvh.root_fold};
+    bvh.nodes4.clear();
+    bvh.root4 = b.root;
+    bvh.stack4 = 0;
+    if (b.nodes.empty() || (b.root & kLeafBit)) return; // single leaf
     struct Box { float lo[3], hi[3]; uint32_t ref; };
     auto area = [](const Box &x) {
         float dx = x.hi[0] - x.lo[0], dy = x.hi[1] - x.lo[1], dz = x.hi[2] - x.lo[2];
@@ -232,13 +314,13 @@ inline void bake_bvh4(BakedBvh &b) {
     std::vector<uint32_t> todo; // binary nodes whose wide node still has to be filled, in allocation order
     auto wide_index = [&](uint32_t node) {
         if (wide_of[node] == 0xFFFFFFFFu) {
-            wide_of[node] = (uint32_t)b.nodes4.size();
-            b.nodes4.emplace_back();
+            wide_of[node] = (uint32_t)bvh.nodes4.size();
+            bvh.nodes4.emplace_back();
             todo.push_back(node);
         }
         return wide_of[node];
     };
-    b.root4 = wide_index(0);
+    bvh.root4 = wide_index(0);
     std::vector<int> need; // stack entries a walk below wide node i may need, filled afterwards
     for (size_t k = 0; k < todo.size(); k++) {
         uint32_t node = todo[k];
@@ -274,12 +356,12 @@ inline void bake_bvh4(BakedBvh &b) {
             else if (src.ref & kLeafBit) w.child[i] = src.ref;
             else w.child[i] = wide_index(src.ref);
         }
-        b.nodes4[wide_of[node]] = w;
+        bvh.nodes4[wide_of[node]] = w;
     }
     // stack bound: children follow parents in allocation order, so one reverse sweep suffices
-    need.assign(b.nodes4.size(), 0);
-    for (size_t k = b.nodes4.size(); k-- > 0;) {
-        const GNode4 &w = b.nodes4[k];
+    need.assign(bvh.nodes4.size(), 0);
+    for (size_t k = bvh.nodes4.size(); k-- > 0;) {
+        const GNode4 &w = bvh.nodes4[k];
         int count = 0, deepest = 0;
         for (int i = 0; i < 4; i++) {
             if (w.child[i] == kNoChild) continue;
@@ -288,7 +370,7 @@ inline void bake_bvh4(BakedBvh &b) {
         }
         need[k] = (count - 1) + deepest;
     }
-    b.stack4 = need[b.root4];
+    bvh.stack4 = need[bvh.root4];
 }
 
 inline void bake_shading(const pt_scene_desc &scene, std::vector<GShade> &shade, std::vector<GMaterial> &mats) {

@@ -735,3 +735,45 @@ def test_failed_configure_is_not_followed_by_a_trusting_one():
     for name in ("tile_rng", "tile_cost", "tile_key", "tile_order"):
         assert f"ctx->{name}.count !=" in guard.split("{")[0], name
         assert f"ctx->{name}.release();" in guard, name
+
+
+def test_leaf_folding_and_wide_fold_cover_every_triangle_once(scene_dir, tmp_path):
+    """layout.h's upload-time transformations on the CPU (no GPU needed): bake_bvh -> fold_leaves(K) -> bake_bvh4 for
+    K = 2 (no folding: the reference's tree unchanged), 4 and 8 on the reference's own cornell tree and on a procedural
+    mesh. Every triangle sits in exactly one leaf of the folded binary tree and of the four-wide tree made from it,
+    no leaf exceeds K, every triangle lies inside the box its parent keeps for its leaf, children follow parents."""
+    so = str(tmp_path / "libfoldcheck.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-I", os.path.join(_ffi.REPO_ROOT, "include"), "-I",
+                           os.path.join(_ffi.REPO_ROOT, "pathtracer_amd", "csrc", "core"), "-o", so,
+                           os.path.join(_ffi.REPO_ROOT, "tests", "native", "fold_check.cpp")])
+    lib = C.CDLL(so)
+    lib.fold_check.argtypes = [C.POINTER(_ffi.SceneDesc), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int64)]
+    for b in (util.golden_cornell(), util.load_bundle(scenes.write_dragon_standin(scene_dir, name="fold_blob", rings=40, segments=40))):
+        nodes, indices = np.ascontiguousarray(b.bvh.nodes), np.ascontiguousarray(b.bvh.indices)
+        stats = {}
+        for k in (2, 4, 8):
+            out = (C.c_int64 * 6)()
+            rc = lib.fold_check(C.byref(b.scene.desc), nodes.ctypes.data, b.bvh.node_count, indices.ctypes.data, len(indices), k, out)
+            assert rc == 0, (k, rc)
+            stats[k] = list(out)
+        assert stats[2][0] == stats[2][5] and stats[2][2] <= 2           # K = 2 leaves the reference's tree as it is
+        assert stats[4][2] <= 4 and stats[8][2] <= 8 and stats[8][2] > 4  # folded leaves are used, within their limit
+        assert stats[8][0] < stats[4][0] < stats[2][0]                     # fewer inner nodes
+        assert stats[8][3] < stats[4][3] < stats[2][3]                     # and fewer wide nodes
+        assert stats[8][4] <= stats[2][4]                                  # the wide walk's stack bound does not grow
+
+
+def test_box_and_triangle_arithmetic_agree_far_inside_the_walk_margins():
+    """the margins of the speculative walks carry a stated safety factor. The oracle's probe
+    (orc_margin_probe) measures, along every ray of a render, how far a leaf box's entry / exit distance lies on the
+    wrong side of the distance Moeller-Trumbore gives for a triangle inside it. Largest over the committed scenes
+    (tools/margins.py -> profiles/r03_margins.md): 2^-19.7 of t. kCullSlack = 2^-13 and kNearHi = 2^-12 are 100 and
+    200 times that; asserted here on two scenes with a bound of 2^-17 (16 times inside kCullSlack)."""
+    for b, res, spp in ((util.golden_cornell(), 128, 8), (util.grazing_scene(), 96, 6)):
+        m = ob.Oracle(b.scene, b.bvh, b.lst, res, res).margin_probe(42, spp, threads=4)
+        assert m["hits"] > 100000 and m["rays"] > 100000
+        assert m["max_entry_behind"] < 2.0 ** -17 and m["max_exit_in_front"] < 2.0 ** -17
+        assert m["culled_by_distance"] == 0  # the reference's own walk never culls a leaf whose triangle is nearer than the best
+        # a triangle hit although its (flat) leaf box is missed: only at t == 0 (a ray leaving a surface whose 1e-6 offset
+        # rounded away), where the box test's `tmax > 0` is what keeps the reference from hitting the surface it leaves
+        assert m["max_t_of_missed_finite"] == 0.0

@@ -5,7 +5,8 @@
 # writes gpurun_out/<tag>_<config>_<arithmetic>/: bench.json (the bench line), stats/ (rocprofv3 --kernel-trace --stats
 # of the same bench command), count.log (instrumented launch: counters + algorithmic bytes), pmc/{f,w,p1..p5}/ (one
 # rocprofv3 --pmc run per counter group, as MI355X_MICROARCH.md asks: no other trace domain alongside, within the
-# per-block counter limits). tools/summarize_profiles.py turns stats/ and pmc/ into the small files under profiles/.
+# per-block counter limits). tools/summarize_profiles.py turns stats/ and pmc/ into kernel_stats.csv and pmc.json there (the databases are
+# deleted: too large to return), which are copied under profiles/.
 set -e
 tag=${1:?tag}
 config=${2:-c2}
@@ -32,5 +33,9 @@ pass p3 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 pass p4 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE
 pass p5 SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP32_TRANS SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32
 cd "$R"
-tail -c 400 "$out/bench.json"
-ls "$out/stats" "$out/pmc"
+# the rocpd databases are tens of MiB each and gpurun_out/ returns at most 64 MiB: summarise here, keep the summaries
+ab=$(grep algorithmic_bytes "$out/count.log" | awk '{print $2}')
+python3 tools/summarize_profiles.py stats "$out/stats/vm_results.db" "$out/kernel_stats.csv" > "$out/summary.log" 2>&1
+python3 tools/summarize_profiles.py pmc "$out/pmc" "$out/pmc.json" "$ab" "rocprofv3 --pmc <pass> -- python3 tools/prof_run.py --config $config --arithmetic $arith $sppflag --batches 2" >> "$out/summary.log" 2>&1
+rm -rf "$out/stats" "$out/pmc"
+tail -c 300 "$out/bench.json"

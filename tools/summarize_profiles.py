@@ -83,6 +83,17 @@ def pmc(root, out, algorithmic=None, command=None):
         der["fabric_GBps"] = der["hbm_traffic_per_launch"] / P["f"]["_duration_ns"]
         if algorithmic:
             der["traffic_over_algorithmic"] = der["hbm_traffic_per_launch"] / float(algorithmic)
+    if "p5" in P and "SQ_INSTS_VALU_FLOPS_FP32" in P["p5"]:
+        # gfx950's FLOPS counters add, per wave-level instruction, the fp32 operations ONE lane performs (packed = 2, fma = 2):
+        # x 64 = what the SIMD issued for, x the lane utilisation = what the active lanes computed
+        f = P["p5"]["SQ_INSTS_VALU_FLOPS_FP32"] + P["p5"].get("SQ_INSTS_VALU_FLOPS_FP32_TRANS", 0.0)
+        der["fp32_flops_issued"] = 64.0 * f
+        if "valu_lane_utilisation" in der:
+            der["fp32_flops_active_lanes"] = 64.0 * f * der["valu_lane_utilisation"]
+        der["fp32_tflops_issued"] = 64.0 * f / P["p5"]["_duration_ns"] / 1e3
+        if "valu_lane_utilisation" in der:
+            der["fp32_tflops_active_lanes"] = der["fp32_tflops_issued"] * der["valu_lane_utilisation"]
+        der["valu_instruction_mix_wave_level"] = {k[len("SQ_INSTS_VALU_"):].lower(): P["p5"][k] for k in P["p5"] if k.startswith("SQ_INSTS_VALU_") and "FLOPS" not in k}
     res["derived"] = der
     with open(out, "w") as f:
         json.dump(res, f, indent=1)

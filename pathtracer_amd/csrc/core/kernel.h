@@ -103,7 +103,13 @@ struct KernelParams {
     const uint32_t *tile_order;
     uint32_t *tile_cost;
     uint32_t *tile_rng; // [tiles][8]: RNG state (v0..v4, d) of each render tile's first pixel for this launch's seed
+
+    // Watchdog (never null in a launch): [0] = waves that gave up because no lane of theirs finished a walk in kWatchdog
+    // consecutive slices, [1..7] = the state of the first such lane. A walk visits every node at most once, so a correct
+    // kernel on a well-formed tree never gets near the limit; a corrupt tree or a bug must not hang the GPU.
+    uint32_t *fault;
 };
+constexpr uint32_t kWatchdog = 1u << 20;
 
 // Everything below exists twice in libptcore.so, compiled from this one source: ptc::exact (ptcore.hip, built with
 // -ffp-contract=off: every float operation rounds as the reference's restatement does, the gate) and ptc::fast
@@ -595,6 +601,18 @@ PT_DEV bool ray_is_exact(f3 d) {
     // 1.0f / x rounds to infinity exactly when |x| <= 2^-128 (zero and the smallest subnormals)
     const float tiny = 0x1p-128f;
     return !WIDE || __builtin_fabsf(d.x) <= tiny || __builtin_fabsf(d.y) <= tiny || __builtin_fabsf(d.z) <= tiny;
+}
+
+PT_DEV void report_stuck(const KernelParams &P, const Walk &w, float t_init, int mode, uint32_t where) {
+    if (atomicAdd(&P.fault[0], 1u) == 0u) {
+        P.fault[1] = w.ref;
+        P.fault[2] = w.pleaf;
+        P.fault[3] = (uint32_t)w.sp;
+        P.fault[4] = (uint32_t)w.h.face;
+        P.fault[5] = __float_as_uint(t_init);
+        P.fault[6] = (uint32_t)mode;
+        P.fault[7] = where;
+    }
 }
 
 PT_DEV void walk_reset(uint32_t root, float t_init, Walk &w) {
@@ -1461,6 +1479,7 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
     Walk wk = {};
     wk.ref = kDone;
     bool walking = false;
+    uint32_t barren = 0; // consecutive slices in which no lane of the wave finished a walk (wave-uniform)
 
     for (;;) {
         // ---- turn boundary: swap the pixel with the one that has waited longest ----
@@ -1533,10 +1552,18 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         walk_slice<COUNT, WIDE>(P, s.ro, s.rd, s.t_init, s.t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
         bool finished = active && wk.ref == kDone && wk.pleaf == 0;
+        barren = __builtin_amdgcn_ballot_w64(finished) != 0 ? 0u : barren + 1u;
+        if (barren > kWatchdog) { // see KernelParams::fault: give the tile up rather than hang the GPU
+            if (active && !finished) report_stuck(P, wk, s.t_init, s.mode, tile);
+            break;
+        }
         // A speculative walk whose winner has another candidate within rounding of it starts over as a sequential
         // one (see kCullSlack). Not after an early exit: whatever is nearest there, the light is hidden.
-        if (!PT_FAST && finished && s.t_init > 0.0f && wk.h.face >= 0 &&
-            ((!wk.h.early && wk.h.t2 <= wk.h.t * kNearHi) || (P.leaf_fold > 2 && hit_on_rim(wk.h)))) {
+        // (Both reasons are evaluated unconditionally and joined with |: written as a short-circuit ||, hipcc 7.2 negated
+        // t_init only on the first reason's lanes and a rim lane walked again, speculatively, for ever.)
+        const bool near_tie = !wk.h.early && wk.h.t2 <= wk.h.t * kNearHi;
+        const bool on_rim = P.leaf_fold > 2 && hit_on_rim(wk.h);
+        if (!PT_FAST && finished && s.t_init > 0.0f && wk.h.face >= 0 && (near_tie | on_rim)) {
             s.t_init = -s.t_init;
             walk_reset(P.root, -s.t_init, wk);
             finished = false;
@@ -1650,11 +1677,16 @@ __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, in
         wk.pleaf = 0;
     }
     uint32_t again = 0;
-    for (;;) {
+    for (uint32_t slices = 0;; slices++) {
         walk_slice<false, WIDE>(P, o, d, t_init, -1.0f, stack, wk, n);
         bool finished = wk.ref == kDone && wk.pleaf == 0;
-        if (!PT_FAST && finished && inside && t_init > 0.0f && wk.h.face >= 0 &&
-            (wk.h.t2 <= wk.h.t * kNearHi || (P.leaf_fold > 2 && hit_on_rim(wk.h)))) {
+        if (slices > kWatchdog) { // see KernelParams::fault
+            if (!finished) report_stuck(P, wk, t_init, -1, blockIdx.x);
+            break;
+        }
+        const bool near_tie = wk.h.t2 <= wk.h.t * kNearHi; // (joined with |, not ||: see render_body)
+        const bool on_rim = P.leaf_fold > 2 && hit_on_rim(wk.h);
+        if (!PT_FAST && finished && inside && t_init > 0.0f && wk.h.face >= 0 && (near_tie | on_rim)) {
             t_init = -t_init;
             walk_reset(P.root, -t_init, wk);
             finished = false;

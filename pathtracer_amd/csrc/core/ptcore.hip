@@ -223,6 +223,7 @@ struct pt_context {
     DeviceArray<uint32_t> jump;
     DeviceArray<float> image;
     DeviceArray<unsigned long long> counters;
+    DeviceArray<uint32_t> fault; // KernelParams::fault: the kernels' watchdog report (8 words, zero while all is well)
     DeviceArray<uint32_t> tile_cost, tile_key, tile_order; // one entry per tile (sized for 8x8 tiles)
     DeviceArray<uint32_t> tile_rng;                        // 8 words per tile
     bool order_valid = false;                    // tile_order holds a permutation for this resolution
@@ -249,6 +250,20 @@ int bind(pt_context *ctx) {
     if (!ctx) return fail("null context");
     HIP_TRY(hipSetDevice(ctx->device));
     return 0;
+}
+
+// After a synchronisation point: did a wave's watchdog fire (KernelParams::fault)? Reports it once and clears it.
+int check_fault(pt_context *ctx, const char *where) {
+    uint32_t f[8];
+    HIP_TRY(hipMemcpy(f, ctx->fault.ptr, sizeof(f), hipMemcpyDeviceToHost));
+    if (f[0] == 0) return 0;
+    uint32_t zero[8] = {0};
+    (void)hipMemcpy(ctx->fault.ptr, zero, sizeof(zero), hipMemcpyHostToDevice);
+    float t;
+    memcpy(&t, &f[5], 4);
+    return fail("%s: %u wavefront(s) gave up on a walk that did not finish in %u slices (first: node reference 0x%08x, parked leaf 0x%08x, "
+                "stack depth %u, best face %d, t_init %g, ray kind %d, tile %u); the image of this launch is incomplete",
+                where, f[0], kWatchdog, f[1], f[2], f[3], (int)f[4], t, (int)f[6], f[7]);
 }
 
 int ready(pt_context *ctx) {
@@ -420,6 +435,9 @@ int create_resources(pt_context *ctx) {
     unsigned long long zeros[32] = {0};
     if (ctx->counters.upload(zeros, 32)) return 1;
     ctx->P.jump = ctx->jump.ptr;
+    uint32_t no_fault[8] = {0};
+    if (ctx->fault.upload(no_fault, 8)) return 1;
+    ctx->P.fault = ctx->fault.ptr;
     if (const char *e = getenv("PT_ARITHMETIC")) // default of new contexts (the CLI has no flag for it: the reference's flag surface is kept)
         if (strcmp(e, "fast") == 0) ctx->kern = &launchers_fast();
     return 0;
@@ -466,6 +484,7 @@ extern "C" void pt_destroy(pt_context *ctx) {
     ctx->jump.release();
     ctx->image.release();
     ctx->counters.release();
+    ctx->fault.release();
     ctx->tile_cost.release();
     ctx->tile_order.release();
     ctx->tile_key.release();
@@ -862,13 +881,13 @@ extern "C" int pt_render_batch(pt_context *ctx, int seed, int previous_samples, 
     if (ready(ctx)) return 1;
     if (pt_render_batch_into(ctx, ctx->image.ptr, nullptr, seed, previous_samples, current_samples)) return 1;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return check_fault(ctx, "pt_render_batch");
 }
 
 extern "C" int pt_synchronize(pt_context *ctx) {
     if (bind(ctx)) return 1;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return check_fault(ctx, "pt_synchronize");
 }
 
 extern "C" float pt_kernel_ms(pt_context *ctx, int launches_back) {
@@ -889,7 +908,7 @@ extern "C" int pt_read_image(pt_context *ctx, float *host_rgb) {
     if (!host_rgb) return fail("pt_read_image: null buffer");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(host_rgb, ctx->image.ptr, ctx->image.bytes(), hipMemcpyDeviceToHost));
-    return 0;
+    return check_fault(ctx, "pt_read_image");
 }
 
 extern "C" int pt_rng_stream(pt_context *ctx, uint64_t seed, uint64_t subsequence, uint32_t *host_out, int n) {
@@ -938,7 +957,7 @@ extern "C" int pt_primary_hits(pt_context *ctx, int seed, int jitter, int tree, 
     (void)hipFree(d_dist);
     if (e != hipSuccess) return fail("HIP error: %s (pt_primary_hits)", hipGetErrorString(e));
     if (redone_walks) *redone_walks = redone;
-    return 0;
+    return check_fault(ctx, "pt_primary_hits");
 }
 
 extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt_counters *out) {
@@ -952,6 +971,7 @@ extern "C" int pt_count_batch(pt_context *ctx, int seed, int current_samples, pt
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (check_fault(ctx, "pt_count_batch")) return 1;
     unsigned long long h[32];
     HIP_TRY(hipMemcpy(h, ctx->counters.ptr, sizeof(h), hipMemcpyDeviceToHost));
     for (int k = 0; k < 6; k++) {
@@ -1166,6 +1186,7 @@ extern "C" int pt_group_render(pt_group *g, int seed, int samples, int samples_e
     for (pt_context *c : g->ctx) {
         GROUP_HIP(hipSetDevice(c->device));
         GROUP_HIP(hipStreamSynchronize(c->stream));
+        if (check_fault(c, "pt_group_render")) return unwind(1);
     }
     (void)hipSetDevice(g->ctx[0]->device);
 #undef GROUP_HIP

@@ -72,9 +72,8 @@ struct Texture {
 
 struct KernelParams {
     // geometry
-    const GNode *nodes;   // the reference's binary tree: rays with an infinite direction reciprocal, sequential re-walks
-    const GNode *nodes_fold; // ... with its bottom levels folded into larger leaves (layout.h fold_leaves): speculative binary walks
-    const GNode4 *nodes4; // the folded tree folded four-wide: every other ray
+    const GNode *nodes;   // binary tree: rays with an infinite direction reciprocal, sequential re-walks, probes
+    const GNode4 *nodes4; // the same tree folded four-wide: every other ray
     const GTri *tris;
     const GShade *shade;
     const GMaterial *materials;
@@ -83,8 +82,7 @@ struct KernelParams {
     const GLight *glights; // one baked record per LST node
     const Texture *textures;
     const uint32_t *jump; // [32][160][8] words: XORWOW A^(2^67 * 2^k), rows padded to 8
-    uint32_t root, root_fold, root4;
-    uint32_t leaf_fold; // > 2: speculative walks test leaves folded from up to that many triangles (see kEdgeBand)
+    uint32_t root, root4;
     uint32_t lst_count;
     uint32_t lst_face_nodes; // LST nodes that are emissive faces (one light-pdf ray each in the reference)
     int32_t clear_texture;
@@ -104,12 +102,19 @@ struct KernelParams {
     uint32_t *tile_cost;
     uint32_t *tile_rng; // [tiles][8]: RNG state (v0..v4, d) of each render tile's first pixel for this launch's seed
 
-    // Watchdog (never null in a launch): [0] = waves that gave up because no lane of theirs finished a walk in kWatchdog
-    // consecutive slices, [1..7] = the state of the first such lane. A walk visits every node at most once, so a correct
-    // kernel on a well-formed tree never gets near the limit; a corrupt tree or a bug must not hang the GPU.
+    // Watchdog of the primary-hit probe (never null in a launch): [0] = waves that gave up on a walk of more than kWatchdog
+    // slices, [1..7] = the state of the first such lane. A walk visits every node at most once and the upload rejects
+    // trees with cycles, so a correct kernel never gets near the limit; a bug must not hang the GPU (one did, in round 3:
+    // a miscompiled short-circuit made a lane walk the same ray for ever). The probe is where a new walk is tried first.
+    // The render kernel carries no such check: two forms of it (a ballot-and-count per slice; a look at the clock every
+    // 2^14 slices, scalar arithmetic only) cost 17 % and 8 % of the launch through the register allocation of its loop
+    // (profiles/r03_kernel_experiments.md).
     uint32_t *fault;
 };
-constexpr uint32_t kWatchdog = 1u << 20;
+constexpr uint32_t kWatchdog = 1u << 20; // slices of one primary-hit walk
+#ifndef PT_WATCHDOG
+#define PT_WATCHDOG 1 /* 0: A/B builds that measure what the check costs */
+#endif
 
 // Everything below exists twice in libptcore.so, compiled from this one source: ptc::exact (ptcore.hip, built with
 // -ffp-contract=off: every float operation rounds as the reference's restatement does, the gate) and ptc::fast
@@ -358,15 +363,6 @@ constexpr float kBand = 1e-4f;
 // noticed nothing has a winner every other candidate loses to in any order and under any culling.
 constexpr float kCullSlack = 1.0f + 0x1p-13f;
 constexpr float kNearHi = 1.0f + 0x1p-12f; // twice the cull slack
-// Leaves folded from the bottom of the tree (layout.h fold_leaves) drop the box tests of the reference's own leaves:
-// a speculative walk then tests triangles whose leaf box the reference's ray may have missed by rounding. That can
-// only be a ray through the rim of the triangle (a point of the triangle with all three barycentric weights above
-// kEdgeBand lies inside its leaf's box by that fraction of the triangle's extent on every axis, a thousand times the
-// rounding of the box test), so a walk whose winner was hit within kEdgeBand of an edge also starts over sequentially.
-constexpr float kEdgeBand = 0x1p-9f;
-PT_DEV bool hit_on_rim(const HitLite &h) {
-    return __builtin_fminf(__builtin_fminf(h.u, h.v), 1.0f - (h.u + h.v)) < kEdgeBand;
-}
 
 struct Tally {
     uint32_t samples, rays, inner, tris, walks, shaded, bounces;
@@ -584,13 +580,9 @@ PT_DEV void test_leaf(const KernelParams &P, uint32_t leaf, f3 o, f3 d, float t_
     float4 a1 = tp[second + 0], b1 = tp[second + 1], c1 = tp[second + 2];
     if (COUNT) n.tris += count;
     test_triangle_pair(a0, b0, c0, a1, b1, c1, count > 1, o, d, t_stop, h);
-    // leaves folded from the bottom of the tree (layout.h fold_leaves) hold up to 8: further pairs, in index order
-    for (uint32_t k = 2; k < count; k += 2) {
+    for (uint32_t k = 2; k < count; k++) { // (a foreign tree's leaves may hold up to 8)
         const float4 *tq = (const float4 *)(P.tris + first + k);
-        const uint32_t other = k + 1 < count ? 3u : 0u;
-        float4 qa0 = tq[0], qb0 = tq[1], qc0 = tq[2];
-        float4 qa1 = tq[other + 0], qb1 = tq[other + 1], qc1 = tq[other + 2];
-        test_triangle_pair(qa0, qb0, qc0, qa1, qb1, qc1, k + 1 < count, o, d, t_stop, h);
+        test_triangle(tq[0], tq[1], tq[2], o, d, t_stop, h);
     }
 }
 
@@ -630,14 +622,10 @@ PT_DEV void walk_reset(uint32_t root, float t_init, Walk &w) {
     }
 }
 
-// true when 1.0f / x is infinite for a component of d: those rays take the reference's select-form box test on the
-// reference's own tree
-PT_DEV bool ray_has_inf_rinv(f3 d) { return ray_is_exact<true>(d); }
-
 template <bool WIDE>
 PT_DEV void walk_begin(const KernelParams &P, f3 d, float &t_init, Walk &w) {
     t_init = __builtin_fabsf(t_init); // a walk sent back to the binary tree leaves it negated (walk_slice)
-    walk_reset(ray_has_inf_rinv(d) ? P.root : (WIDE ? P.root4 : P.root_fold), t_init, w);
+    walk_reset(ray_is_exact<WIDE>(d) ? P.root : P.root4, t_init, w);
 }
 
 template <bool COUNT, bool WIDE, class STK>
@@ -746,8 +734,7 @@ PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_
                     PT_MARK("binary_step begin");
                     // the reference's binary tree; with an infinite reciprocal (a zero direction component) its
                     // exact select-form test, where 0 * inf = NaN decides as in intersect_aabb
-                    // (the reference's own tree for the select-form test and for sequential re-walks, the leaf-folded one otherwise)
-                    const float4 *np = (const float4 *)(((inf_rinv || seq) ? P.nodes : P.nodes_fold) + w.ref);
+                    const float4 *np = (const float4 *)(P.nodes + w.ref);
                     float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                     float t1, t2;
                     if (!inf_rinv) {
@@ -1479,7 +1466,6 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
     Walk wk = {};
     wk.ref = kDone;
     bool walking = false;
-    uint32_t barren = 0; // consecutive slices in which no lane of the wave finished a walk (wave-uniform)
 
     for (;;) {
         // ---- turn boundary: swap the pixel with the one that has waited longest ----
@@ -1552,18 +1538,9 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
         walk_slice<COUNT, WIDE>(P, s.ro, s.rd, s.t_init, s.t_stop, stack, wk, n);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
         bool finished = active && wk.ref == kDone && wk.pleaf == 0;
-        barren = __builtin_amdgcn_ballot_w64(finished) != 0 ? 0u : barren + 1u;
-        if (barren > kWatchdog) { // see KernelParams::fault: give the tile up rather than hang the GPU
-            if (active && !finished) report_stuck(P, wk, s.t_init, s.mode, tile);
-            break;
-        }
         // A speculative walk whose winner has another candidate within rounding of it starts over as a sequential
         // one (see kCullSlack). Not after an early exit: whatever is nearest there, the light is hidden.
-        // (Both reasons are evaluated unconditionally and joined with |: written as a short-circuit ||, hipcc 7.2 negated
-        // t_init only on the first reason's lanes and a rim lane walked again, speculatively, for ever.)
-        const bool near_tie = !wk.h.early && wk.h.t2 <= wk.h.t * kNearHi;
-        const bool on_rim = P.leaf_fold > 2 && hit_on_rim(wk.h);
-        if (!PT_FAST && finished && s.t_init > 0.0f && wk.h.face >= 0 && (near_tie | on_rim)) {
+        if (!PT_FAST && finished && s.t_init > 0.0f && !wk.h.early && wk.h.face >= 0 && wk.h.t2 <= wk.h.t * kNearHi) {
             s.t_init = -s.t_init;
             walk_reset(P.root, -s.t_init, wk);
             finished = false;
@@ -1680,13 +1657,11 @@ __global__ void __launch_bounds__(kBlock) primary_hits_kernel(KernelParams P, in
     for (uint32_t slices = 0;; slices++) {
         walk_slice<false, WIDE>(P, o, d, t_init, -1.0f, stack, wk, n);
         bool finished = wk.ref == kDone && wk.pleaf == 0;
-        if (slices > kWatchdog) { // see KernelParams::fault
+        if (PT_WATCHDOG && slices > kWatchdog) { // see KernelParams::fault
             if (!finished) report_stuck(P, wk, t_init, -1, blockIdx.x);
             break;
         }
-        const bool near_tie = wk.h.t2 <= wk.h.t * kNearHi; // (joined with |, not ||: see render_body)
-        const bool on_rim = P.leaf_fold > 2 && hit_on_rim(wk.h);
-        if (!PT_FAST && finished && inside && t_init > 0.0f && wk.h.face >= 0 && (near_tie | on_rim)) {
+        if (!PT_FAST && finished && inside && t_init > 0.0f && wk.h.face >= 0 && wk.h.t2 <= wk.h.t * kNearHi) {
             t_init = -t_init;
             walk_reset(P.root, -t_init, wk);
             finished = false;

@@ -121,11 +121,6 @@ struct BakedBvh {
     std::vector<GTri> tris;
     uint32_t root = 0; // child reference of the root
     int height = 0;    // nodes on the longest root-to-leaf path
-    // The same binary tree with its bottom levels folded into leaves of up to `fold` triangles (fold_leaves): what
-    // SPECULATIVE walks use, directly (binary form) or folded four-wide (nodes4). Equal to nodes / root when fold <= 2.
-    std::vector<GNode> nodes_fold;
-    uint32_t root_fold = 0;
-    uint32_t fold = 0;
     std::vector<GNode4> nodes4;
     uint32_t root4 = 0;   // child reference of the wide root (a leaf reference when the tree is one leaf)
     int stack4 = 0;       // most stack entries a wide walk can hold at once
@@ -212,85 +207,12 @@ inline std::string bake_bvh(const std::vector<GShade> &shade, const pt_bvh_node 
     return "";
 }
 
-// Folds the bottom of the baked binary tree into larger leaves: an inner node whose subtree holds at most max_tris
-// triangles (<= 8, the leaf format's limit) in ONE contiguous run of the triangle array becomes a leaf reference in
-// its parent. The reference builder partitions index ranges in place (bvh.cu:136-192), so every subtree of its
-// trees is such a run; a foreign tree whose subtrees are scattered simply folds nowhere. The reference's leaves
-// hold at most 2 faces (bvh.cu:143): its walk then pays an inner-node visit (two box tests, a 64-byte fetch, a
-// stack operation) to choose between two leaves of one or two triangles each, where testing the four triangles
-// costs about the same arithmetic in half the steps. Only speculative walks use the folded form; the sequential
-// re-walk that settles near-ties follows the reference's own tree (nodes / root), so the reference's visiting order
-// is untouched where it matters. Call after bake_bvh, before bake_bvh4.
-inline void fold_leaves(BakedBvh &b, uint32_t max_tris) {
-    b.nodes_fold.clear();
-    b.root_fold = b.root;
-    b.fold = max_tris;
-    if (max_tris > kMaxLeafTris) max_tris = kMaxLeafTris;
-    if (b.nodes.empty() || max_tris <= 2) {
-        b.nodes_fold = b.nodes;
-        return;
-    }
-    const size_t n = b.nodes.size();
-    std::vector<uint32_t> first(n), count(n);
-    std::vector<char> run(n);
-    auto span = [&](uint32_t ref, uint32_t *f, uint32_t *c, bool *r) {
-        if (ref & kLeafBit) {
-            *f = ref & 0x0FFFFFFFu;
-            *c = ((ref >> 28) & 7u) + 1u;
-            *r = true;
-        } else {
-            *f = first[ref];
-            *c = count[ref];
-            *r = run[ref] != 0;
-        }
-    };
-    for (size_t k = n; k-- > 0;) { // children follow parents
-        uint32_t fl, cl, fr, cr;
-        bool rl, rr;
-        span(b.nodes[k].left, &fl, &cl, &rl);
-        span(b.nodes[k].right, &fr, &cr, &rr);
-        first[k] = fl < fr ? fl : fr;
-        count[k] = cl + cr;
-        run[k] = rl && rr && (fl + cl == fr || fr + cr == fl);
-    }
-    auto folds = [&](uint32_t ref) { return !(ref & kLeafBit) && run[ref] && count[ref] <= max_tris; };
-    if (folds(0)) { // the whole tree is one leaf
-        b.root_fold = leaf_ref(first[0], count[0]);
-        return;
-    }
-    // nodes that survive: reachable from the root without passing a folded node; dense remap in the old order
-    std::vector<uint32_t> remap(n, 0xFFFFFFFFu);
-    std::vector<char> keep(n, 0);
-    keep[0] = 1;
-    for (size_t k = 0; k < n; k++) {
-        if (!keep[k]) continue;
-        const uint32_t c[2] = {b.nodes[k].left, b.nodes[k].right};
-        for (uint32_t ref : c)
-            if (!(ref & kLeafBit) && !folds(ref)) keep[ref] = 1;
-    }
-    uint32_t kept = 0;
-    for (size_t k = 0; k < n; k++)
-        if (keep[k]) remap[k] = kept++;
-    b.nodes_fold.resize(kept);
-    for (size_t k = 0; k < n; k++) {
-        if (!keep[k]) continue;
-        GNode g = b.nodes[k];
-        uint32_t *c[2] = {&g.left, &g.right};
-        for (uint32_t *ref : c) {
-            if (*ref & kLeafBit) continue;
-            *ref = folds(*ref) ? leaf_ref(first[*ref], count[*ref]) : remap[*ref];
-        }
-        b.nodes_fold[remap[k]] = g;
-    }
-    b.root_fold = 0;
-}
-
-// Folds the (leaf-folded) binary tree into four-wide nodes. Call after bake_bvh and fold_leaves.
+// Folds the baked binary tree into four-wide nodes. Call after bake_bvh.
 inline void bake_bvh4(BakedBvh &bvh) {
     struct Source { // the binary tree the wide one is made from
         const std::vector<GNode> &nodes;
         uint32_t root;
-    } b{bvh.nodes_fold, bvh.root_fold};
+    } b{bvh.nodes, bvh.root};
     bvh.nodes4.clear();
     bvh.root4 = b.root;
     bvh.stack4 = 0;

@@ -206,8 +206,6 @@ struct pt_context {
     std::vector<uint32_t> h_light_mult; // per face: times listed in the LST
 
     DeviceArray<GNode> nodes;
-    DeviceArray<GNode> nodes_fold;
-    uint32_t leaf_fold = 0; // triangles per folded leaf of the uploaded tree (<= 2: not folded)
     DeviceArray<GNode4> nodes4;
     DeviceArray<GTri> tris;
     DeviceArray<GShade> shade;
@@ -261,9 +259,9 @@ int check_fault(pt_context *ctx, const char *where) {
     (void)hipMemcpy(ctx->fault.ptr, zero, sizeof(zero), hipMemcpyHostToDevice);
     float t;
     memcpy(&t, &f[5], 4);
-    return fail("%s: %u wavefront(s) gave up on a walk that did not finish in %u slices (first: node reference 0x%08x, parked leaf 0x%08x, "
-                "stack depth %u, best face %d, t_init %g, ray kind %d, tile %u); the image of this launch is incomplete",
-                where, f[0], kWatchdog, f[1], f[2], f[3], (int)f[4], t, (int)f[6], f[7]);
+    return fail("%s: the watchdog of %u wavefront(s) fired (first: node reference 0x%08x, parked leaf 0x%08x, stack depth %u, best face %d, "
+                "t_init %g, ray kind %d, tile %u); the image of this launch is incomplete",
+                where, f[0], f[1], f[2], f[3], (int)f[4], t, (int)f[6], f[7]);
 }
 
 int ready(pt_context *ctx) {
@@ -472,7 +470,6 @@ extern "C" void pt_destroy(pt_context *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release();
     ctx->nodes4.release();
-    ctx->nodes_fold.release();
     ctx->tris.release();
     ctx->shade.release();
     ctx->materials.release();
@@ -602,10 +599,6 @@ extern "C" int pt_bvh_upload(pt_context *ctx, const pt_bvh_node *nodes, uint32_t
     if (!err.empty()) return fail("pt_bvh_upload: %s", err.c_str());
     // the reference refuses trees taller than its 64-entry stack (bvh.cu:338-342)
     if (baked.height > 65) return fail("pt_bvh_upload: tree height %d exceeds the 64-entry traversal stack", baked.height);
-    // PT_LEAF_TRIS=4..8 folds the bottom of the tree into larger leaves for speculative walks (layout.h fold_leaves)
-    uint32_t leaf_tris = 2;
-    if (const char *e = getenv("PT_LEAF_TRIS")) leaf_tris = (uint32_t)atoi(e);
-    fold_leaves(baked, leaf_tris < 2 ? 2 : (leaf_tris > kMaxLeafTris ? kMaxLeafTris : leaf_tris));
     bake_bvh4(baked);
     // stack entries a walk may hold: height - 1 in the binary tree; in the four-wide one the folded bound
     // (every sibling hit on the whole path) plus the 2 scratch slots the wide step writes above the top
@@ -614,13 +607,9 @@ extern "C" int pt_bvh_upload(pt_context *ctx, const pt_bvh_node *nodes, uint32_t
     if (stack_need > 64) return fail("pt_bvh_upload: a walk of this tree can need %d stack entries (64 available)", stack_need);
     if (ctx->nodes.upload(baked.nodes.data(), baked.nodes.size())) return 1;
     if (ctx->nodes4.upload(baked.nodes4.data(), baked.nodes4.size())) return 1;
-    if (ctx->nodes_fold.upload(baked.nodes_fold.data(), baked.nodes_fold.size())) return 1;
     ctx->P.nodes4 = ctx->nodes4.ptr;
     ctx->P.root4 = baked.root4;
-    ctx->P.nodes_fold = ctx->nodes_fold.ptr;
-    ctx->P.root_fold = baked.root_fold;
-    ctx->leaf_fold = baked.fold;
-    ctx->P.leaf_fold = baked.fold;
+
     ctx->stack_need = stack_need;
     ctx->stack_need4 = stack_need4;
     ctx->tree_at_upload = 0;
@@ -1214,7 +1203,7 @@ extern "C" int pt_arithmetic(pt_context *ctx) { return (ctx && ctx->kern == &lau
 
 extern "C" uint64_t pt_device_footprint(pt_context *ctx) {
     if (!ctx) return 0;
-    return ctx->nodes.bytes() + ctx->nodes_fold.bytes() + ctx->nodes4.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
+    return ctx->nodes.bytes() + ctx->nodes4.bytes() + ctx->tris.bytes() + ctx->shade.bytes() + ctx->materials.bytes() + ctx->lights.bytes() +
            ctx->lst.bytes() + ctx->glights.bytes() + ctx->textures.bytes() + ctx->texel_bytes + ctx->jump.bytes() + ctx->image.bytes() +
            ctx->tile_cost.bytes() + ctx->tile_key.bytes() + ctx->tile_order.bytes() + ctx->tile_rng.bytes();
 }

@@ -1,7 +1,7 @@
 // fold_check.cpp — CPU check of the upload-time tree transformations in pathtracer_amd/csrc/core/layout.h
-// (bake_bvh -> fold_leaves -> bake_bvh4). Test infrastructure: built by tests/test_oracle_and_host.py with g++.
-// Returns 0 and fills `out` = {folded inner nodes, folded leaves, largest leaf, wide nodes, wide stack bound,
-// binary inner nodes} or a negative code naming the invariant that failed.
+// (bake_bvh -> bake_bvh4). Test infrastructure: built by tests/test_oracle_and_host.py with g++.
+// Returns 0 and fills `out` = {binary inner nodes, leaves, largest leaf, wide nodes, wide stack bound, tree height}
+// or a negative code naming the invariant that failed.
 #include <cstdint>
 #include <vector>
 
@@ -38,24 +38,23 @@ bool inside(const float *lo, const float *hi, const GTri &t) {
 } // namespace
 
 extern "C" int fold_check(const pt_scene_desc *scene, const pt_bvh_node *nodes, uint32_t node_count, const uint32_t *indices,
-                          uint32_t index_count, uint32_t max_tris, int64_t *out) {
+                          uint32_t index_count, int64_t *out) {
     std::vector<GShade> shade;
     std::vector<GMaterial> mats;
     bake_shading(*scene, shade, mats);
     BakedBvh b;
     if (!bake_bvh(shade, nodes, node_count, indices, index_count, b).empty()) return -1;
-    fold_leaves(b, max_tris);
     bake_bvh4(b);
-    const uint32_t limit = max_tris < 2 ? 2 : (max_tris > 8 ? 8 : max_tris);
-    // folded binary tree: every triangle in exactly one leaf, leaves within the limit, every triangle inside the box
+    const uint32_t limit = 8; // the leaf format's limit (the reference's builder stops at 2, bvh.cu:143)
+    // binary tree: every triangle in exactly one leaf, leaves within the limit, every triangle inside the box
     // its parent holds for it, children after parents
     Cover c;
     c.seen.assign(index_count, 0);
-    if (b.root_fold & kLeafBit) {
-        if (!c.leaf(b.root_fold, limit)) return -2;
+    if (b.root & kLeafBit) {
+        if (!c.leaf(b.root, limit)) return -2;
     } else {
-        for (size_t k = 0; k < b.nodes_fold.size(); k++) {
-            const GNode &g = b.nodes_fold[k];
+        for (size_t k = 0; k < b.nodes.size(); k++) {
+            const GNode &g = b.nodes[k];
             const uint32_t ref[2] = {g.left, g.right};
             const float *lo[2] = {g.lmin, g.rmin}, *hi[2] = {g.lmax, g.rmax};
             for (int s = 0; s < 2; s++) {
@@ -64,14 +63,13 @@ extern "C" int fold_check(const pt_scene_desc *scene, const pt_bvh_node *nodes, 
                     uint32_t first = ref[s] & 0x0FFFFFFFu, count = ((ref[s] >> 28) & 7u) + 1u;
                     for (uint32_t i = 0; i < count; i++)
                         if (!inside(lo[s], hi[s], b.tris[first + i])) return -4;
-                } else if (ref[s] <= k || ref[s] >= b.nodes_fold.size()) {
+                } else if (ref[s] <= k || ref[s] >= b.nodes.size()) {
                     return -5;
                 }
             }
         }
     }
     if (!c.all_once()) return -6;
-    if (max_tris <= 2 && (b.nodes_fold.size() != b.nodes.size() || b.root_fold != b.root)) return -7;
     // four-wide tree: the same cover, through two to four children per node
     Cover w;
     w.seen.assign(index_count, 0);
@@ -98,11 +96,11 @@ extern "C" int fold_check(const pt_scene_desc *scene, const pt_bvh_node *nodes, 
         }
     }
     if (!w.all_once()) return -13;
-    out[0] = (int64_t)b.nodes_fold.size();
+    out[0] = (int64_t)b.nodes.size();
     out[1] = c.leaves;
     out[2] = c.largest;
     out[3] = (int64_t)b.nodes4.size();
     out[4] = b.stack4;
-    out[5] = (int64_t)b.nodes.size();
+    out[5] = b.height;
     return 0;
 }

@@ -737,30 +737,28 @@ def test_failed_configure_is_not_followed_by_a_trusting_one():
         assert f"ctx->{name}.release();" in guard, name
 
 
-def test_leaf_folding_and_wide_fold_cover_every_triangle_once(scene_dir, tmp_path):
-    """layout.h's upload-time transformations on the CPU (no GPU needed): bake_bvh -> fold_leaves(K) -> bake_bvh4 for
-    K = 2 (no folding: the reference's tree unchanged), 4 and 8 on the reference's own cornell tree and on a procedural
-    mesh. Every triangle sits in exactly one leaf of the folded binary tree and of the four-wide tree made from it,
-    no leaf exceeds K, every triangle lies inside the box its parent keeps for its leaf, children follow parents."""
+def test_baked_trees_cover_every_triangle_once(scene_dir, tmp_path):
+    """layout.h's upload-time transformations on the CPU (no GPU needed): bake_bvh -> bake_bvh4 on the reference's own
+    cornell tree and on a procedural mesh. Every triangle sits in exactly one leaf of the baked binary tree and of the
+    four-wide tree folded from it, every triangle lies inside the box its parent keeps for its leaf, children follow
+    parents, every wide node has two to four children, and the wide walk's stack bound is what pt_bvh_upload sizes
+    the LDS stack from."""
     so = str(tmp_path / "libfoldcheck.so")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-I", os.path.join(_ffi.REPO_ROOT, "include"), "-I",
                            os.path.join(_ffi.REPO_ROOT, "pathtracer_amd", "csrc", "core"), "-o", so,
                            os.path.join(_ffi.REPO_ROOT, "tests", "native", "fold_check.cpp")])
     lib = C.CDLL(so)
-    lib.fold_check.argtypes = [C.POINTER(_ffi.SceneDesc), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int64)]
-    for b in (util.golden_cornell(), util.load_bundle(scenes.write_dragon_standin(scene_dir, name="fold_blob", rings=40, segments=40))):
+    lib.fold_check.argtypes = [C.POINTER(_ffi.SceneDesc), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_int64)]
+    for b, nodes_want in ((util.golden_cornell(), 2215), (util.load_bundle(scenes.write_dragon_standin(scene_dir, name="fold_blob", rings=40, segments=40)), None)):
         nodes, indices = np.ascontiguousarray(b.bvh.nodes), np.ascontiguousarray(b.bvh.indices)
-        stats = {}
-        for k in (2, 4, 8):
-            out = (C.c_int64 * 6)()
-            rc = lib.fold_check(C.byref(b.scene.desc), nodes.ctypes.data, b.bvh.node_count, indices.ctypes.data, len(indices), k, out)
-            assert rc == 0, (k, rc)
-            stats[k] = list(out)
-        assert stats[2][0] == stats[2][5] and stats[2][2] <= 2           # K = 2 leaves the reference's tree as it is
-        assert stats[4][2] <= 4 and stats[8][2] <= 8 and stats[8][2] > 4  # folded leaves are used, within their limit
-        assert stats[8][0] < stats[4][0] < stats[2][0]                     # fewer inner nodes
-        assert stats[8][3] < stats[4][3] < stats[2][3]                     # and fewer wide nodes
-        assert stats[8][4] <= stats[2][4]                                  # the wide walk's stack bound does not grow
+        out = (C.c_int64 * 6)()
+        rc = lib.fold_check(C.byref(b.scene.desc), nodes.ctypes.data, b.bvh.node_count, indices.ctypes.data, len(indices), out)
+        assert rc == 0, rc
+        inner, leaves, largest, wide, stack4, height = list(out)
+        assert inner + leaves == b.bvh.node_count and leaves == inner + 1 and largest <= 2  # the reference's builder: leaves of 1 or 2 faces
+        if nodes_want:
+            assert b.bvh.node_count == nodes_want and height == 16                          # SURVEY.md section 3.3
+        assert inner / 3 <= wide < inner and 0 < stack4 <= 3 * (height - 1)               # two to four children per wide node
 
 
 def test_box_and_triangle_arithmetic_agree_far_inside_the_walk_margins():

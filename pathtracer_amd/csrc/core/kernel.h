@@ -625,16 +625,27 @@ PT_DEV void walk_reset(uint32_t root, float t_init, Walk &w) {
 template <bool WIDE>
 PT_DEV void walk_begin(const KernelParams &P, f3 d, float &t_init, Walk &w) {
     t_init = __builtin_fabsf(t_init); // a walk sent back to the binary tree leaves it negated (walk_slice)
-    walk_reset(ray_is_exact<WIDE>(d) ? P.root : P.root4, t_init, w);
+    walk_reset((PT_FAST ? !WIDE : ray_is_exact<WIDE>(d)) ? P.root : P.root4, t_init, w);
 }
 
 template <bool COUNT, bool WIDE, class STK>
 PT_DEV void walk_slice(const KernelParams &P, f3 o, f3 d, float t_init, float t_stop, STK &stack, Walk &w, Tally &n) {
+#if PT_FAST
+    // Tolerance arithmetic has no use for the reference's 0 * inf = NaN rules: a zero direction component is nudged to
+    // +-2^-64 (every plane distance stays finite), every ray takes the same box test on the same tree, and there are no
+    // sequential re-walks: in a four-wide kernel the binary step below is not even compiled.
+    const float nudge = 0x1p-64f;
+    f3 rinv = mk3(rcp_exact(__builtin_fabsf(d.x) < nudge ? __builtin_copysignf(nudge, d.x) : d.x),
+                  rcp_exact(__builtin_fabsf(d.y) < nudge ? __builtin_copysignf(nudge, d.y) : d.y),
+                  rcp_exact(__builtin_fabsf(d.z) < nudge ? __builtin_copysignf(nudge, d.z) : d.z));
+    constexpr bool inf_rinv = false, seq = false, exact = !WIDE;
+#else
     f3 rinv = mk3(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z));
     const float inf = __builtin_inff();
     const bool inf_rinv = __builtin_fabsf(rinv.x) == inf || __builtin_fabsf(rinv.y) == inf || __builtin_fabsf(rinv.z) == inf;
     const bool seq = t_init < 0.0f;                  // sequential walk (see kCullSlack)
     const bool exact = !WIDE || inf_rinv || seq;      // walks the binary tree
+#endif
 #if PT_FAST
     const f3 orr = o * rinv; // (NaN where 0 * inf: only for rays that take the select-form test below, which does not use it)
 #endif
@@ -984,7 +995,7 @@ __global__ void __launch_bounds__(256) tile_key_kernel(const uint32_t *__restric
     uint32_t msb = 31u - (uint32_t)__builtin_clz(c);
     uint32_t cls = msb * 4u + ((c >> (msb - 2u)) & 3u); // <= 127
     uint32_t tx = t % ntx, ty = t / ntx;
-    uint32_t w0 = (nty % 8u == 0) ? ((ty / 8u) * ntx + tx) * 8u + (ty % 8u) : t; // inverse of pixel_of_thread's static map
+    uint32_t w0 = (nty % 8u == 0) ? ((ty / 8u) * ntx + tx) * 8u + (ty % 8u) : t; // inverse of tile_of_wave's static map
     key[t] = ((127u - cls) << 24) | w0;
 }
 

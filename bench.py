@@ -314,6 +314,13 @@ def main():
                          "useful_issue_frac": round(prof["valu_useful_issue"], 4) if "valu_useful_issue" in prof else None,
                          "wave_instructions_per_launch": int(prof["valu_wave_instructions"]) if "valu_wave_instructions" in prof else None,
                          "l2_hit_rate": round(prof["l2_hit_rate"], 4) if "l2_hit_rate" in prof else None,
+                         # the same quantity from gfx950's own FLOPS counters (SQ_INSTS_VALU_FLOPS_FP32 + _TRANS of the profiled
+                         # launch: add / mul / fma / transcendental only, no compares or min / max): what the SIMDs issued for
+                         # all 64 lanes, and the share the active lanes computed
+                         "hw_counter_tflops_issued": round(prof["fp32_tflops_issued"], 3) if "fp32_tflops_issued" in prof else None,
+                         "hw_counter_tflops_active_lanes": round(prof["fp32_tflops_active_lanes"], 3) if "fp32_tflops_active_lanes" in prof else None,
+                         "resident_waves_per_simd": round(prof["resident_waves_per_simd"], 3) if "resident_waves_per_simd" in prof else None,
+                         "wave_cycle_shares": {k: round(v, 4) for k, v in prof["wave_cycle_shares"].items()} if "wave_cycle_shares" in prof else None,
                          "counters_source": prof_src, "live_lane_utilisation_instrumented": live_lanes},
             # Contract form: algorithmic bytes / launch time against the HBM peak. The bytes are served by
             # L2 / Infinity Cache (fabric traffic is a fraction of them), so this fraction does not bind.

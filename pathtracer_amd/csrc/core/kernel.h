@@ -458,7 +458,7 @@ constexpr uint32_t kDone = 0x7FFFFFFFu; // not a node index (< 2^28 triangles =>
 #define PT_SLICE 12
 #endif
 #ifndef PT_SLICE_WIDE
-#define PT_SLICE_WIDE 6
+#define PT_SLICE_WIDE (PT_FAST ? 5 : 6) /* measured per arithmetic (profiles/r03_kernel_experiments.md) */
 #endif
 #ifndef PT_SHADE_NUM
 #define PT_SHADE_NUM 1 /* shade when finished lanes / live lanes >= NUM / DEN (0 = as soon as any lane finished) */

@@ -7,9 +7,9 @@ The JOB is fixed (strong scaling, the reference's own metric: README.md:29-59, b
 K batches ("steps") of the configuration's samples-every-update, batch b seeded 42 + b, rendered in index order on
 one GPU, or sharded b mod N over N GPUs (one rank per GPU, launched by torch.distributed.run) with the per-rank
 accumulators combined by ONE RCCL sum all-reduce inside the timed region. value = W*H*spp_total / elapsed, the same
-job at every N. When N > K a batch is split so that every rank has one (c2 at N = 8: 8 batches of 25 spp instead of
-4 of 50, as SURVEY.md section 8e prescribes; the line says so in config.spp_per_batch). --weak keeps round 2's
-behaviour: K batches PER RANK.
+job at every N. Batches that do not fill a whole round of N are cut into N equal parts, so every rank renders the same
+number of samples (c2 at N = 8: 8 batches of 25 spp instead of 4 of 50, as SURVEY.md section 8e prescribes; the line
+lists the sizes in config.batch_sizes). --weak keeps round 2's behaviour: K batches PER RANK.
 
   c2 (default)  many_lights STAND-IN 1024x1024, batches of 50 spp (K = 4: the README's 200 spp)
   c3            the reference's dragon.gltf (golden arrays) 1024x1024, batches of 64 spp (K = 8: 512 spp)
@@ -71,14 +71,24 @@ def load_config_scene(name):
 
 
 def plan_job(steps, spp_step, world, weak):
-    """(spp_per_batch, batches in the whole job). Strong: the job is steps x spp_step samples per pixel whatever the
-    number of ranks; a batch is split evenly when there are fewer batches than ranks. Weak: steps batches per rank."""
+    """Samples per batch of every batch of the whole job, in batch order (batch b runs on rank b mod world with seed
+    42 + b). Strong: the job is steps x spp_step samples per pixel whatever the number of ranks. Whole rounds of `world`
+    batches keep the configuration's samples-every-update; the batches left over (steps mod world of them, all of them
+    when steps < world) are cut into `world` equal parts, one per rank, so that every rank renders the same number of
+    samples (c2 at N = 8: 8 batches of 25 spp instead of 4 of 50; 20 steps at N = 8: 16 batches of
+    50 + 8 of 25). A remainder that does not divide leaves parts that differ by one sample. Weak: steps batches per rank."""
     if weak:
-        return spp_step, steps * world
-    split = -(-world // steps) if steps < world else 1
-    spp_batch = max(1, spp_step // split)
-    total = steps * spp_step
-    return spp_batch, -(-total // spp_batch)
+        return [spp_step] * (steps * world)
+    sizes = [spp_step] * (steps // world * world)
+    left = (steps % world) * spp_step
+    if left:
+        sizes += [s for s in (left // world + (1 if r < left % world else 0) for r in range(world)) if s > 0]
+    return sizes
+
+
+def plan_rank(sizes, rank, world):
+    """[(batch index, seed offset, samples)] of this rank, in launch order: render.plan_batches for batches of given sizes."""
+    return [(b, b, n) for b, n in enumerate(sizes) if b % world == rank]
 
 
 def algorithmic_bytes(c, width, height, tree=2):
@@ -221,9 +231,9 @@ def main():
         torch.cuda.synchronize(device)
 
     # ---- the job: which batches exist, and which are this rank's ------------------------------
-    spp_batch, n_batches = plan_job(steps, cfg["spp"], world, args.weak)
-    spp_total = spp_batch * n_batches if args.weak else steps * cfg["spp"]
-    plan = render.plan_batches(spp_total, spp_batch, rank, world)  # [(b, seed offset, samples)]: batch b on rank b mod N
+    sizes = plan_job(steps, cfg["spp"], world, args.weak)
+    spp_total, n_batches, spp_batch = sum(sizes), len(sizes), sizes[0]
+    plan = plan_rank(sizes, rank, world)  # [(b, seed offset, samples)]: batch b on rank b mod N
 
     # ---- warmup (untimed; the first launch also times both forms of the tree and records tile costs) ----
     for i in range(args.warmup):
@@ -240,7 +250,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     # HIP events the library recorded around every launch, on the stream it was launched on
-    kernel_ms = [r.kernel_ms(k) for k in range(min(len(plan), 64))]
+    # (launch k back is plan[-1 - k]; the per-batch figures below are of the batches of batch 0's size)
+    kernel_ms = [r.kernel_ms(k) for k in range(min(len(plan), 64)) if plan[-1 - k][2] == spp_batch]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -278,14 +289,15 @@ def main():
                   "tolerance arithmetic: u32 RNG stream bit-exact, primary-hit ids and image error against the oracle stated in "
                   "tests/test_gpu_tolerance.py and DESIGN.md section 3")
         out = {
-            "metric": f"Msamples/s (node) {cfg['label'].split(' (')[0]} {width}x{height}, {spp_total} spp in batches of {spp_batch}",
+            "metric": f"Msamples/s (node) {cfg['label'].split(' (')[0]} {width}x{height}, {spp_total} spp in {n_batches} batches",
             "value": round(samples / elapsed / 1e6, 3),
             "unit": "Msamples/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['label']} {width}x{height}, {spp_total} spp in {n_batches} batches of "
-                                   f"{spp_batch} spp, seed 42+batch, batch b on rank b mod {world}",
-                       "resolution": [width, height], "spp_per_batch": spp_batch, "batches": n_batches, "spp_total": spp_total,
+                                   f"{'/'.join(str(x) for x in sorted(set(sizes), reverse=True))} spp, seed 42+batch, batch b on rank b mod {world}",
+                       "resolution": [width, height], "spp_per_batch": spp_batch, "batch_sizes": sizes if len(sizes) <= 64 else sizes[:64] + ["..."],
+                       "batches": n_batches, "spp_total": spp_total, "spp_on_rank0": sum(n for _, _, n in plan),
                        "batches_on_rank0": len(plan), "parallelism": f"sample-shard x{world}", "arithmetic": args.arithmetic,
                        "walk_tree": tree, "bvh_nodes": int(bvh.node_count), "faces": int(len(scene.faces)), "lst_nodes": int(len(lst.nodes)),
                        "parity": parity},

@@ -43,15 +43,18 @@ def test_two_ranks_render_and_combine_on_the_gpu(tmp_path):
 
 
 def test_bench_loop_two_ranks_equals_one_rank(tmp_path):
-    """bench.py's OWN loop (plan_job -> plan_batches -> render_local -> combine) with two ranks on the box's one GPU
-    (gloo; the driver's N > 1 runs use RCCL) against the same command with one rank: the same fixed job (3 batches
-    of 5 spp: a ragged 2 + 1 split), the same image to fp32 summation order, value = the whole job's samples / time."""
+    """bench.py's OWN loop (plan_job -> plan_rank -> render_local -> combine) with two ranks on the box's one GPU
+    (gloo; the driver's N > 1 runs use RCCL) against the same command with one rank: the same fixed job (4 batches of
+    5 spp: two whole rounds, so the batches and their seeds are the same at both N), the same image to fp32 summation
+    order, value = the whole job's samples / time. (Batches that do NOT fill a round are cut into N parts, which
+    changes their seeds: then the image is another estimate of the same picture; tests/test_distributed_cpu.py
+    checks those plans.)"""
     import json
     if core.CONTEXTS_CREATED:
         pytest.skip("GPU already initialised in this process; run this file first or alone")
     env = dict(os.environ, OMP_NUM_THREADS="4")
     bench = os.path.join(_ffi.REPO_ROOT, "bench.py")
-    common = ["--config", "c1", "--res", "160", "--spp", "5", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-tolerance"]
+    common = ["--config", "c1", "--res", "160", "--spp", "5", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-tolerance"]
     lines = {}
     for n in (1, 2):
         with socket.socket() as s:
@@ -68,7 +71,8 @@ def test_bench_loop_two_ranks_equals_one_rank(tmp_path):
     assert np.abs(two.astype(np.float64) - one).max() <= 2e-6 * np.abs(one).max()
     for n in (1, 2):
         ln = lines[n]
-        assert ln["scaling"] == "strong" and ln["n_gpus"] == n and ln["steps"] == 3
-        assert ln["config"]["spp_total"] == 15 and ln["config"]["batches"] == 3 and ln["config"]["spp_per_batch"] == 5
-        assert abs(ln["value"] - 160 * 160 * 15 / ln["elapsed_s"] / 1e6) <= 1e-2 * ln["value"]
-    assert lines[1]["config"]["batches_on_rank0"] == 3 and lines[2]["config"]["batches_on_rank0"] == 2
+        assert ln["scaling"] == "strong" and ln["n_gpus"] == n and ln["steps"] == 4
+        assert ln["config"]["spp_total"] == 20 and ln["config"]["spp_per_batch"] == 5 and ln["config"]["batch_sizes"] == [5, 5, 5, 5]
+        assert abs(ln["value"] - 160 * 160 * 20 / ln["elapsed_s"] / 1e6) <= 1e-2 * ln["value"]
+    assert lines[1]["config"]["batches_on_rank0"] == 4 and lines[2]["config"]["batches_on_rank0"] == 2
+    assert lines[1]["config"]["spp_on_rank0"] == 20 and lines[2]["config"]["spp_on_rank0"] == 10

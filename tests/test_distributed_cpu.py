@@ -78,22 +78,26 @@ def test_two_rank_shard_and_reduce_matches_single_process(tmp_path):
 
 
 def test_bench_job_plan_is_the_same_job_at_every_rank_count():
-    """bench.py's strong-scaling job: K batches of the configuration's spp in total, whatever N; a batch is split
-    only when there are fewer batches than ranks (c2 at N = 8: 8 x 25 spp), and every rank's
-    share follows plan_batches (batch b on rank b mod N, seed 42 + b)."""
+    """bench.py's strong-scaling job: K batches of the configuration's spp in total, whatever N. Whole rounds of N
+    batches keep their size; what is left over is cut into N equal parts (c2 at N = 8: 8 x 25 spp, SURVEY.md section
+    8e; 20 steps at N = 8: 16 x 50 + 8 x 25), so every rank renders the same number of samples (differing by one
+    sample at most when the remainder does not divide), batch b on rank b mod N with seed 42 + b."""
     import bench
-    for steps, spp, world, want in ((4, 50, 1, (50, 4)), (4, 50, 2, (50, 4)), (4, 50, 4, (50, 4)), (4, 50, 8, (25, 8)),
-                                    (8, 128, 8, (128, 8)), (20, 50, 8, (50, 20)), (1, 16, 2, (8, 2)), (3, 50, 8, (16, 10))):
-        spp_batch, n = bench.plan_job(steps, spp, world, weak=False)
-        assert (spp_batch, n) == want, (steps, spp, world, spp_batch, n)
-        total = steps * spp
-        plans = [render.plan_batches(total, spp_batch, r, world) for r in range(world)]
-        assert sorted(b for p in plans for b, _, _ in p) == list(range(n))
-        assert sum(c for p in plans for _, _, c in p) == total          # the same job at every N
-        assert all(len(p) >= 1 for p in plans) or n < world
-        sizes = [len(p) for p in plans]
-        assert max(sizes) - min(sizes) <= 1                              # ragged splits differ by one batch at most
-    assert bench.plan_job(4, 50, 8, weak=True) == (50, 32)               # --weak: K batches per rank
+    cases = ((4, 50, 1, [50] * 4), (4, 50, 2, [50] * 4), (4, 50, 4, [50] * 4), (4, 50, 8, [25] * 8), (8, 128, 8, [128] * 8),
+             (20, 50, 8, [50] * 16 + [25] * 8), (1, 16, 2, [8, 8]), (3, 50, 8, [19] * 6 + [18] * 2), (3, 5, 2, [5, 5, 3, 2]),
+             (1, 3, 8, [1, 1, 1]), (9, 64, 4, [64] * 8 + [16] * 4))
+    for steps, spp, world, want in cases:
+        sizes = bench.plan_job(steps, spp, world, weak=False)
+        assert sizes == want, (steps, spp, world, sizes)
+        assert sum(sizes) == steps * spp                                   # the same job at every N
+        plans = [bench.plan_rank(sizes, r, world) for r in range(world)]
+        assert sorted(b for p in plans for b, _, _ in p) == list(range(len(sizes)))
+        assert all(off == b for p in plans for b, off, _ in p)             # seed 42 + b, as main.cu:121
+        load = [sum(n for _, _, n in p) for p in plans]
+        assert max(load) - min(load) <= 1, load                           # every rank renders the same number of samples
+    sizes = bench.plan_job(4, 50, 3, weak=False)                           # uniform sizes: the partition is plan_batches's
+    assert [bench.plan_rank([50] * 4, r, 3) for r in range(3)] == [render.plan_batches(200, 50, r, 3) for r in range(3)]
+    assert bench.plan_job(4, 50, 8, weak=True) == [50] * 32                # --weak: K batches per rank
 
 
 def test_group_plan_is_the_reference_loop_sharded_by_batch():

@@ -213,7 +213,9 @@ int pt_walk_tree(pt_context *ctx);
  * hardware's 1-ulp reciprocal / root, no tie bookkeeping in the walk): what nvcc's default contraction gives the
  * reference itself (bvh.cu:222-237, intersect.cu:12-81, mathops.h:114-121). Same RNG stream bit for bit; primary
  * hits and image agree with the exact variant within the tolerances stated in tests/test_gpu_tolerance.py.
- * PT_ARITHMETIC=fast in the environment makes it the default of new contexts. Waits for the context's stream. */
+ * PT_ARITHMETIC=fast in the environment makes it the default of new contexts. Waits for the context's own stream; a
+ * caller that launches on its own stream (pt_render_batch_into) switches between launches it has synchronised. The
+ * next render launch times the two forms of the tree again for the new variant (blocks the host ~10 ms). */
 #define PT_ARITHMETIC_EXACT 0
 #define PT_ARITHMETIC_FAST 1
 int pt_set_arithmetic(pt_context *ctx, int arithmetic);

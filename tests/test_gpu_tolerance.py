@@ -16,6 +16,8 @@ Measured on the box (round 3, profiles/r03_tolerance.log):
     handful of pixels whose paths did flip), mean relative error 1.3e-6, against 0.054 between two seeds.
 The bounds asserted below leave room for other flips than the ones this run met.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -157,3 +159,55 @@ def test_switching_arithmetic_back_restores_bit_identity(cornell_bundle):
     finally:
         r.close()
     assert util.count_different(first, cpu) == 0 and util.count_different(again, cpu) == 0
+
+
+def test_fast_arithmetic_through_every_entry_point_agrees_with_itself(cornell_bundle):
+    """The tolerance variant behind each way of launching it: pt_render_batch, pt_render_batch_into on a caller stream,
+    pt_render_batch_static and a pt_group of one device give the same floats (its arithmetic is deterministic: tile
+    order, tree form and entry point change nothing), and an unknown arithmetic is refused."""
+    import torch
+    b = cornell_bundle
+    w, h, seed, spp, every = 88, 72, 11, 9, 4
+    r = _renderer(b, w, h, "fast")
+    try:
+        want = r.render(seed, spp, every)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            acc = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+            acc2 = torch.zeros_like(acc)
+            done, s = 0, seed
+            while done < spp:
+                cur = min(every, spp - done)
+                r.render_batch_into(acc.data_ptr(), s, done, cur, side.cuda_stream)
+                r.render_batch_static(acc2.data_ptr(), w, h, s, done, cur, side.cuda_stream)
+                done, s = done + cur, s + 1
+            side.synchronize()
+        assert np.array_equal(util.bits(acc.cpu().numpy().reshape(h, w, 3)), util.bits(want))
+        assert np.array_equal(util.bits(acc2.cpu().numpy().reshape(h, w, 3)), util.bits(want))
+        for tree in ("binary", "wide"):  # the other form of the tree: same floats (no tie bookkeeping, but the same candidates)
+            os.environ["PT_TREE"] = tree
+            try:
+                r2 = _renderer(b, w, h, "fast")
+                try:
+                    other = r2.render(seed, spp, every)
+                finally:
+                    r2.close()
+            finally:
+                del os.environ["PT_TREE"]
+            same = float((util.bits(other) == util.bits(want)).mean())
+            print(f"fast arithmetic, PT_TREE={tree}: {same * 100:.2f} % of floats identical to the timed choice")
+            assert same > 0.9  # a walk's winner can differ between the trees only in an exact tie
+        with pytest.raises(core.CoreError):
+            core._check(r._lib.pt_set_arithmetic(r._ctx, 7))
+        assert r.arithmetic() == "fast"
+    finally:
+        r.close()
+    g = core.Group([0])
+    try:
+        for rr in g.ranks:
+            rr.set_arithmetic("fast")
+        g.upload(b.scene, b.bvh, b.lst)
+        g.configure(w, h)
+        assert np.array_equal(util.bits(g.render(seed, spp, every)), util.bits(want))
+    finally:
+        g.close()

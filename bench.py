@@ -271,7 +271,11 @@ def main():
         abytes = algorithmic_bytes(counters, width, height, tree)
         achieved = abytes / (avg_ms * 1e-3) / 1e9
         prof, prof_src = pmc_profile(cfg["profile_key"], args.arithmetic)
-        traffic = int(prof["hbm_traffic_per_launch"]) if "hbm_traffic_per_launch" in prof else None
+        # the profiled launch may have fewer samples per pixel than this batch (c5 is profiled at 16 spp, one GPU's share
+        # of a 128-spp batch): per-launch counter totals scale with the samples, ratios do not
+        m = re.search(r"_(\d+)spp", prof_src or "")
+        prof_scale = spp_batch / float(m.group(1)) if m else 1.0
+        traffic = int(prof["hbm_traffic_per_launch"] * prof_scale) if "hbm_traffic_per_launch" in prof else None
         isa, isa_src = newest_profile(f"r*_isa_flops_{args.arithmetic}*.json")
         flops, flop_parts = algorithmic_flops(counters, tree, isa)
         tflops = flops / (avg_ms * 1e-3) / 1e12 if flops else None
@@ -324,7 +328,8 @@ def main():
                          "busy": round(prof["valu_busy"], 4) if "valu_busy" in prof else None,
                          "lane_utilisation": round(prof["valu_lane_utilisation"], 4) if "valu_lane_utilisation" in prof else None,
                          "useful_issue_frac": round(prof["valu_useful_issue"], 4) if "valu_useful_issue" in prof else None,
-                         "wave_instructions_per_launch": int(prof["valu_wave_instructions"]) if "valu_wave_instructions" in prof else None,
+                         "wave_instructions_per_launch": int(prof["valu_wave_instructions"] * prof_scale) if "valu_wave_instructions" in prof else None,
+                         "counters_scaled_by": round(prof_scale, 4),
                          "l2_hit_rate": round(prof["l2_hit_rate"], 4) if "l2_hit_rate" in prof else None,
                          # the same quantity from gfx950's own FLOPS counters (SQ_INSTS_VALU_FLOPS_FP32 + _TRANS of the profiled
                          # launch: add / mul / fma / transcendental only, no compares or min / max): what the SIMDs issued for

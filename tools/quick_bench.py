@@ -14,7 +14,7 @@ ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--spp", type=int, default=50)
 ap.add_argument("--count", action="store_true")
 a = ap.parse_args()
-tag = f"{os.environ.get('PT_CORE_LIB', 'libptcore.so')} kernel={os.environ.get('PT_KERNEL', 'mega')} rows={os.environ.get('PT_POOL_ROWS', '-')}"
+tag = f"{os.environ.get('PT_CORE_LIB', 'libptcore.so')} kernel={os.environ.get('PT_KERNEL', 'mega')} stream={os.environ.get('PT_STREAM', '0')} lpt={os.environ.get('PT_LPT', '1')}"
 for name in a.scenes.split(","):
     with tempfile.TemporaryDirectory() as d:
         if name == "many_lights":

@@ -295,6 +295,9 @@ void set_launch(KernelParams &P, int seed, int prev, int cur, int jitter) {
 // PT_LPT=0 in the environment keeps the static tile order (A/B measurements)
 const bool g_lpt = []() { const char *e = getenv("PT_LPT"); return !(e && e[0] == '0'); }();
 
+// samples per pixel of the two launches that time the trees (render_launches); PT_TUNE_SAMPLES overrides
+const int g_tune_samples = []() { const char *e = getenv("PT_TUNE_SAMPLES"); int n = e ? atoi(e) : 2; return n >= 1 && n <= 8 ? n : 2; }();
+
 // 8 or 16 pixel rows per tile (see pt_configure). PT_TILE_ROWS in the environment forces one.
 int pick_tile_rows(int width, int height, int cus) {
     size_t tiles16 = (size_t)((width + 7) / 8) * (size_t)((height + 15) / 16);
@@ -765,7 +768,7 @@ int render_launches(pt_context *ctx, KernelParams &P, TileScratch &ts, float *im
         // time a 2-sample launch without an image on each and keep the faster. Blocks the host once per
         // uploaded tree (about 10 ms).
         float ms[2] = {0.f, 0.f};
-        P.current_samples = 2;
+        P.current_samples = g_tune_samples;
         for (int k = 0; k < 2; k++) {
             HIP_TRY(hipEventRecord(ctx->ev_tune[0], st));
             launch_probe(ctx, P, ts, st, k == 1);
@@ -774,6 +777,7 @@ int render_launches(pt_context *ctx, KernelParams &P, TileScratch &ts, float *im
             HIP_TRY(hipEventElapsedTime(&ms[k], ctx->ev_tune[0], ctx->ev_tune[1]));
         }
         ctx->walk_tree = ms[1] < ms[0] ? 4 : 2;
+        if (getenv("PT_VERBOSE")) fprintf(stderr, "[ptcore] tree timing, %d sample(s): binary %.3f ms, four-wide %.3f ms\n", g_tune_samples, ms[0], ms[1]);
         P.current_samples = current_samples;
         if (g_lpt && !ts.order_valid) launch_rank(P, ts, st); // the second probe's tile costs order the first batch
     } else if (ctx->walk_tree == 0 && may_block) {

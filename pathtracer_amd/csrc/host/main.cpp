@@ -185,21 +185,31 @@ int main(int argc, char *argv[]) {
     int rendered = 0, batch = 0;
     while (rendered < cfg.samples) {
         int current = cfg.samples_every_update < cfg.samples - rendered ? cfg.samples_every_update : cfg.samples - rendered;
+        auto t0 = std::chrono::steady_clock::now();
         CORE_TRY(pt_render_batch(ctx, cfg.seed, rendered, current));
         kernel_seconds += pt_last_kernel_ms(ctx) / 1000.0;
+        auto t1 = std::chrono::steady_clock::now();
         float *buf = buffers[batch & 1];
         CORE_TRY(pt_read_image(ctx, buf));
+        auto t2 = std::chrono::steady_clock::now();
         rendered += current;
         cfg.seed++;
         batch++;
         if (worker.joinable()) worker.join();
         if (worker_failed) exit(EXIT_FAILURE);
+        auto t3 = std::chrono::steady_clock::now();
+        pth_log(4, "Batch %d on the main thread: launch to kernel end %.2f ms (kernel %.2f), copy back %.2f ms, waited for the writer %.2f ms\n", batch,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), pt_last_kernel_ms(ctx),
+                std::chrono::duration<double, std::milli>(t2 - t1).count(), std::chrono::duration<double, std::milli>(t3 - t2).count());
         worker = std::thread([&, buf, rendered, kernel_seconds]() {
+            auto w0 = std::chrono::steady_clock::now();
             if (pth_write_image(buf, cfg.resolution_x, cfg.resolution_y, cfg.path_render)) {
                 pth_log(1, "%s\n", pth_last_error());
                 worker_failed = true;
                 return;
             }
+            pth_log(4, "Tonemap + PNG on the writer thread: %.2f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
             auto now = std::chrono::system_clock::now();
             int elapsed_ms = (int)std::chrono::duration_cast<std::chrono::milliseconds>(now - start).count();
             float elapsed = elapsed_ms / 1000.0f;

@@ -775,3 +775,33 @@ def test_box_and_triangle_arithmetic_agree_far_inside_the_walk_margins():
         # a triangle hit although its (flat) leaf box is missed: only at t == 0 (a ray leaving a surface whose 1e-6 offset
         # rounded away), where the box test's `tmax > 0` is what keeps the reference from hitting the surface it leaves
         assert m["max_t_of_missed_finite"] == 0.0
+
+
+def test_png_writer_checksums_and_stored_blocks_against_zlib(tmp_path, monkeypatch):
+    """pth_write_png_rgb8 computes Adler-32 and CRC-32 on row blocks in parallel and combines the partial sums
+    (image_io.cpp). Every chunk's CRC, the zlib stream (zlib.decompress also checks its Adler-32) and the filtered
+    rows are checked against Python's zlib, for shapes that put block boundaries (65 535 raw bytes) inside rows, at
+    row ends and nowhere, on one thread and on many."""
+    import struct
+    import zlib
+    lib = _ffi.host_lib()
+    rng = np.random.default_rng(3)
+    path = str(tmp_path / "t.png")
+    for (w, h) in [(1, 1), (7, 5), (300, 200), (21845, 1), (3, 21846), (1000, 1100), (1024, 1024)]:
+        for threads in ("1", "16"):
+            monkeypatch.setenv("PTH_BUILD_THREADS", threads)
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            assert lib.pth_write_png_rgb8(img.ctypes.data_as(C.c_void_p), w, h, path.encode()) == 0
+            d = open(path, "rb").read()
+            assert d[:8] == bytes([137, 80, 78, 71, 13, 10, 26, 10])
+            at, chunks = 8, []
+            while at < len(d):
+                n, = struct.unpack(">I", d[at:at + 4])
+                kind, body = d[at + 4:at + 8], d[at + 8:at + 8 + n]
+                crc, = struct.unpack(">I", d[at + 8 + n:at + 12 + n])
+                assert zlib.crc32(kind + body) == crc, (w, h, threads, kind)
+                chunks.append((kind, body))
+                at += 12 + n
+            assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+            assert chunks[0][1] == struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)
+            assert zlib.decompress(chunks[1][1]) == b"".join(b"\0" + img[y].tobytes() for y in range(h)), (w, h, threads)

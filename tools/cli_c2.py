@@ -15,10 +15,10 @@ with tempfile.TemporaryDirectory() as d:
     argv = [os.path.join(_ffi.REPO_ROOT, "bin", "pathtracer"), "--path-gltf", gltf, "--dir-output", out,
             "--output-resolution-x", "1024", "--output-resolution-y", "1024", "--sampling-samples", sys.argv[1] if len(sys.argv) > 1 else "200",
             "--sampling-samples-every-update", "50", "--sampling-seed", "42", "--output-exposure", "0",
-            "--world-clear-color", "0 0 0", "--world-clear-color-texture", "", "--logger-log-level", "3", "--logger-log-stdout", "0",
+            "--world-clear-color", "0 0 0", "--world-clear-color-texture", "", "--logger-log-level", os.environ.get("PT_CLI_LOG_LEVEL", "3"), "--logger-log-stdout", "0",
             "--default-camera-position", "0 0 5", "--default-camera-target", "0 0 0", "--default-camera-updir", "0 1 0",
             "--default-camera-yfov", "0.7"]
     r = subprocess.run(argv, capture_output=True, text=True)
     print("rc", r.returncode, r.stderr[-500:])
-    print(open(os.path.join(out, "log.txt")).read()[-1800:])
+    print(open(os.path.join(out, "log.txt")).read()[-3500:])
     print("render.png bytes", os.path.getsize(os.path.join(out, "render.png")))

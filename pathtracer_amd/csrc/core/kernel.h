@@ -1330,6 +1330,10 @@ PT_DEV bool vertex_handler(const KernelParams &P, HitLite hit, Path &s, Tally &n
     return end_path;
 }
 
+#ifndef PT_PRIO_WALK
+#define PT_PRIO_WALK 1 /* s_setprio of a wave inside walk_slice ... */
+#define PT_PRIO_SHADE 0 /* ... and everywhere else (render_body) */
+#endif
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 3
 #endif
@@ -1546,7 +1550,13 @@ PT_DEV void render_body(const KernelParams &P, float *__restrict__ img, unsigned
             if (COUNT) n.walks++;
             walking = true;
         }
+        // The walk issues the wave's dependent fetches (a node, then its nearest child, ...); shading is long stretches
+        // of arithmetic. With the walk at the higher issue priority a wave's next fetch leaves as soon as the last one
+        // is back, and the SIMD's other waves shade in the gaps: 1.4 - 1.8 % per launch on every scene measured
+        // (profiles/r03_kernel_experiments.md; priorities 2 / 3, or node and leaf phases apart, give the same).
+        __builtin_amdgcn_s_setprio(PT_PRIO_WALK);
         walk_slice<COUNT, WIDE>(P, s.ro, s.rd, s.t_init, s.t_stop, stack, wk, n);
+        __builtin_amdgcn_s_setprio(PT_PRIO_SHADE);
         region_time<COUNT>(n, kRegLoop, tl0, stamp<COUNT>());
         bool finished = active && wk.ref == kDone && wk.pleaf == 0;
         // A speculative walk whose winner has another candidate within rounding of it starts over as a sequential

@@ -1153,10 +1153,17 @@ extern "C" int pt_group_render(pt_group *g, int seed, int samples, int samples_e
         GROUP_HIP(hipMemsetAsync(c->image.ptr, 0, c->image.bytes(), c->stream));
     }
     // the reference's batch loop (main.cu:101-133), batch b on rank b mod n: all launches are asynchronous on
-    // their context's stream, so the GPUs render side by side (the first launch of each context blocks the host
-    // for about 10 ms while it times the two forms of the tree: n x 10 ms at the start of the first render)
+    // their context's stream, so the GPUs render side by side. The first launch of a context that has not chosen
+    // the form of its tree yet blocks the host for about 8 ms while it times both: rank 0 (batch 0 is its) does
+    // that once, and a rank that holds the same tree under the same arithmetic takes rank 0's answer instead of
+    // timing it again, one device after the other (n x 8 ms before the GPUs would all be rendering).
     for (const pt_group_batch &b : plan) {
         pt_context *c = g->ctx[(size_t)b.rank];
+        const pt_context *c0 = g->ctx[0];
+        if (c != c0 && c->walk_tree == 0 && c0->walk_tree != 0 && c->kern == c0->kern && c->tree_at_upload == 0 &&
+            c->coincident == c0->coincident && c->nodes.count == c0->nodes.count && c->nodes4.count == c0->nodes4.count &&
+            c->tris.count == c0->tris.count && c->stack_need == c0->stack_need && c->stack_need4 == c0->stack_need4)
+            c->walk_tree = c0->walk_tree;
         if (pt_render_batch_into(c, c->image.ptr, nullptr, b.seed, b.previous_samples, b.current_samples)) return unwind(1);
     }
     // weight every rank's mean by its share of the samples, then ONE sum-reduce to rank 0

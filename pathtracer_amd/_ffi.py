@@ -199,6 +199,10 @@ def core_lib():
     L.pt_group_context.restype = C.c_void_p
     L.pt_group_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.pt_read_image.argtypes = [C.c_void_p, C.c_void_p]
+    L.pt_host_alloc.argtypes = [C.c_size_t]
+    L.pt_host_alloc.restype = C.c_void_p
+    L.pt_host_free.argtypes = [C.c_void_p]
+    L.pt_host_free.restype = None
     L.pt_clear_image.argtypes = [C.c_void_p]
     L.pt_synchronize.argtypes = [C.c_void_p]
     L.pt_rng_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]

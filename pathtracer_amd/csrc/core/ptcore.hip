@@ -905,6 +905,20 @@ extern "C" int pt_read_image(pt_context *ctx, float *host_rgb) {
     return 0;
 }
 
+extern "C" void *pt_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        fail("pt_host_alloc: %s (%zu bytes)", hipGetErrorString(e), bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void pt_host_free(void *ptr) {
+    if (ptr) (void)hipHostFree(ptr);
+}
+
 extern "C" int pt_rng_stream(pt_context *ctx, uint64_t seed, uint64_t subsequence, uint32_t *host_out, int n) {
     if (bind(ctx)) return 1;
     if (!host_out || n <= 0) return fail("pt_rng_stream: bad arguments");

@@ -176,8 +176,12 @@ int main(int argc, char *argv[]) {
     // as a 50-spp launch at 1024^2) runs on a worker thread beside the next batch's kernel: the main thread
     // reads batch k into one of two host buffers, waits until the worker is done with batch k-1, hands
     // over, and launches batch k+1. Every "Rendered ..." line is still printed once its PNG is on disk.
-    std::vector<float> h_img2(pixels * 3);
-    float *buffers[2] = {h_img.data(), h_img2.data()};
+    // The two host buffers are page-locked where the runtime grants it (the copy back then runs at the DMA engine's
+    // rate); pageable memory otherwise, as in the reference (main.cu:86).
+    std::vector<float> h_img2;
+    float *pinned[2] = {(float *)pt_host_alloc(pixels * 3 * sizeof(float)), (float *)pt_host_alloc(pixels * 3 * sizeof(float))};
+    if (!pinned[1]) h_img2.resize(pixels * 3);
+    float *buffers[2] = {pinned[0] ? pinned[0] : h_img.data(), pinned[1] ? pinned[1] : h_img2.data()};
     auto start = std::chrono::system_clock::now();
     std::thread worker;
     bool worker_failed = false;
@@ -226,6 +230,8 @@ int main(int argc, char *argv[]) {
     if (worker_failed) exit(EXIT_FAILURE);
     // ########## DISPATCH #############
 
+    pt_host_free(pinned[0]);
+    pt_host_free(pinned[1]);
     pt_destroy(ctx);
     pth_free(lst);
     pth_bvh_free(&bvh);

@@ -103,6 +103,27 @@ def test_cornell_like_image_exact(renderer, cornell_like):
     _assert_images_match(renderer.read_image(), cpu)
 
 
+def test_read_image_into_page_locked_memory(renderer, cornell_like):
+    """pt_host_alloc / pt_host_free (what bin/pathtracer reads its batches into): the same floats as a read into
+    pageable memory, and a null pointer frees as nothing."""
+    import ctypes as C
+    w, h = 72, 40
+    _setup(renderer, cornell_like, w, h)
+    renderer.clear()
+    renderer.render_batch(5, 0, 3)
+    want = renderer.read_image()
+    lib = renderer._lib
+    p = lib.pt_host_alloc(w * h * 3 * 4)
+    assert p
+    try:
+        assert lib.pt_read_image(renderer._ctx, p) == 0
+        got = np.frombuffer((C.c_float * (w * h * 3)).from_address(p), np.float32).reshape(h, w, 3).copy()
+    finally:
+        lib.pt_host_free(p)
+    lib.pt_host_free(None)
+    assert np.array_equal(util.bits(got), util.bits(want))
+
+
 def test_running_mean_over_batches(renderer, cornell_like):
     """main.cu:101-133: seed + 1 per batch, running mean, ragged last batch."""
     w, h = 80, 48  # not multiples of the 16x16 block

@@ -95,7 +95,8 @@ int pt_configure(pt_context *ctx, const pt_render_config *cfg);
  * fixed 16x16 block order, src/main.cu:85-88, leaves the device draining behind its slowest
  * blocks). The first render launch after pt_bvh_upload first runs two short launches that write
  * no pixel (they time the binary and the four-wide form of the tree, see pt_walk_tree, and record
- * tile costs) and blocks the host for about 10 ms while it reads the two timings.
+ * tile costs; at half the image size when the image is large, the same view through a quarter of the
+ * pixels) and blocks the host for about 5 ms while it reads the two timings.
  * Pixels depend on none of this. PT_LPT=0 in the environment keeps the static order.
  *
  * render_kernel<<<grid, block>>>(d_img, d_bvh, d_scene, d_lst, cfg, prev, cur)
@@ -222,7 +223,7 @@ int pt_walk_tree(pt_context *ctx);
  * hits and image agree with the exact variant within the tolerances stated in tests/test_gpu_tolerance.py.
  * PT_ARITHMETIC=fast in the environment makes it the default of new contexts. Waits for the context's own stream; a
  * caller that launches on its own stream (pt_render_batch_into) switches between launches it has synchronised. The
- * next render launch times the two forms of the tree again for the new variant (blocks the host ~10 ms). */
+ * next render launch times the two forms of the tree again for the new variant (blocks the host ~5 ms). */
 #define PT_ARITHMETIC_EXACT 0
 #define PT_ARITHMETIC_FAST 1
 int pt_set_arithmetic(pt_context *ctx, int arithmetic);

@@ -1018,6 +1018,15 @@ __global__ void __launch_bounds__(64) tile_order_kernel(const uint32_t *__restri
     if (i < n) order[rank[i]] = i;
 }
 
+// Tile costs recorded at half the image size (render_launches), spread over the full-size tiles each one covers.
+__global__ void __launch_bounds__(256) tile_expand_kernel(const uint32_t *__restrict__ half, uint32_t *__restrict__ full, uint32_t ntx,
+                                                          uint32_t nty, uint32_t htx, uint32_t hty) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= ntx * nty) return;
+    uint32_t x = (t % ntx) / 2u, y = (t / ntx) / 2u;
+    full[t] = half[(y < hty ? y : hty - 1u) * htx + (x < htx ? x : htx - 1u)];
+}
+
 #endif // !PT_FAST
 
 PT_DEV void camera_ray(const KernelParams &P, float u, float v, f3 *o, f3 *d) {

@@ -295,6 +295,9 @@ void set_launch(KernelParams &P, int seed, int prev, int cur, int jitter) {
 // PT_LPT=0 in the environment keeps the static tile order (A/B measurements)
 const bool g_lpt = []() { const char *e = getenv("PT_LPT"); return !(e && e[0] == '0'); }();
 
+// PT_HALF_PROBE=0: time the trees at the full image size whatever it is (A/B measurements)
+const bool g_half_probe = []() { const char *e = getenv("PT_HALF_PROBE"); return !(e && e[0] == '0'); }();
+
 // samples per pixel of the two launches that time the trees (render_launches); PT_TUNE_SAMPLES overrides
 const int g_tune_samples = []() { const char *e = getenv("PT_TUNE_SAMPLES"); int n = e ? atoi(e) : 2; return n >= 1 && n <= 8 ? n : 2; }();
 
@@ -757,7 +760,7 @@ extern "C" int pt_clear_image(pt_context *ctx) {
 namespace {
 // One render launch of `P` with its tile scratch `ts` on `st`: the launches around it that record tile
 // costs and rank them, and the HIP events of pt_kernel_ms. may_block: the first launch after an upload may
-// time both trees (blocks the host for about 10 ms); otherwise an untimed choice is made.
+// time both trees (blocks the host for about 5 ms); otherwise an untimed choice is made.
 int render_launches(pt_context *ctx, KernelParams &P, TileScratch &ts, float *img, hipStream_t st, bool may_block) {
     const int current_samples = P.current_samples;
     const int slot = (int)(ctx->launches % pt_context::kEventRing);
@@ -766,18 +769,37 @@ int render_launches(pt_context *ctx, KernelParams &P, TileScratch &ts, float *im
         // Which tree walks this scene faster depends on the scene (four-wide: half the node visits, but
         // fewer lanes stepping together; measured both ways, -12 % .. +7 %). Both give the same hits, so
         // time a 2-sample launch without an image on each and keep the faster. Blocks the host once per
-        // uploaded tree (about 10 ms).
+        // uploaded tree (about 5 ms).
+        // A large image is timed at half its resolution: the same view through a quarter of the pixels (the camera
+        // maps pixel to direction by the image size, renderer.cu:380-386), a quarter of the time, and still more
+        // tiles than the GPU holds waves. Its tile costs stand in for the 2 x 2 full-size tiles each one covers.
         float ms[2] = {0.f, 0.f};
-        P.current_samples = g_tune_samples;
+        uint32_t ntx, nty;
+        render_tiles(P, ts.rows, &ntx, &nty);
+        const bool half = g_half_probe && (size_t)ntx * nty >= 4 * (size_t)ctx->cus * 4 * PT_MIN_WAVES;
+        KernelParams Q = P;
+        TileScratch tq = ts;
+        if (half) {
+            Q.width = (P.width + 1) / 2;
+            Q.height = (P.height + 1) / 2;
+            tq.cost = ts.key; // (free until launch_rank builds the keys)
+        }
+        Q.current_samples = g_tune_samples;
         for (int k = 0; k < 2; k++) {
             HIP_TRY(hipEventRecord(ctx->ev_tune[0], st));
-            launch_probe(ctx, P, ts, st, k == 1);
+            launch_probe(ctx, Q, tq, st, k == 1);
             HIP_TRY(hipEventRecord(ctx->ev_tune[1], st));
             HIP_TRY(hipEventSynchronize(ctx->ev_tune[1]));
             HIP_TRY(hipEventElapsedTime(&ms[k], ctx->ev_tune[0], ctx->ev_tune[1]));
         }
+        if (half) {
+            uint32_t htx, hty;
+            render_tiles(Q, ts.rows, &htx, &hty);
+            hipLaunchKernelGGL(tile_expand_kernel, dim3((ntx * nty + 255u) / 256u), dim3(256), 0, st, tq.cost, ts.cost, ntx, nty, htx, hty);
+        }
         ctx->walk_tree = ms[1] < ms[0] ? 4 : 2;
-        if (getenv("PT_VERBOSE")) fprintf(stderr, "[ptcore] tree timing, %d sample(s): binary %.3f ms, four-wide %.3f ms\n", g_tune_samples, ms[0], ms[1]);
+        if (getenv("PT_VERBOSE"))
+            fprintf(stderr, "[ptcore] tree timing at %d x %d, %d sample(s): binary %.3f ms, four-wide %.3f ms\n", Q.width, Q.height, g_tune_samples, ms[0], ms[1]);
         P.current_samples = current_samples;
         if (g_lpt && !ts.order_valid) launch_rank(P, ts, st); // the second probe's tile costs order the first batch
     } else if (ctx->walk_tree == 0 && may_block) {
@@ -1168,7 +1190,7 @@ extern "C" int pt_group_render(pt_group *g, int seed, int samples, int samples_e
     }
     // the reference's batch loop (main.cu:101-133), batch b on rank b mod n: all launches are asynchronous on
     // their context's stream, so the GPUs render side by side. The first launch of a context that has not chosen
-    // the form of its tree yet blocks the host for about 8 ms while it times both: rank 0 (batch 0 is its) does
+    // the form of its tree yet blocks the host for about 5 ms while it times both: rank 0 (batch 0 is its) does
     // that once, and a rank that holds the same tree under the same arithmetic takes rank 0's answer instead of
     // timing it again, one device after the other (n x 8 ms before the GPUs would all be rendering).
     for (const pt_group_batch &b : plan) {

@@ -435,11 +435,13 @@ inline float srgb_gamma(float c) {
 
 namespace {
 
-// Row ranges on a few threads (PTH_BUILD_THREADS caps them, as for the BVH builder).
+// Row ranges on a few threads (PTH_BUILD_THREADS caps them, as for the BVH builder): fn(t, y0, y1) with
+// t < kRowThreads, block t before block t + 1.
+constexpr int kRowThreads = 16;
 template <typename F> void for_row_blocks(int height, F fn) {
     unsigned want = std::thread::hardware_concurrency();
     if (const char *e = getenv("PTH_BUILD_THREADS")) want = (unsigned)atoi(e);
-    if (want > 16) want = 16;
+    if (want > (unsigned)kRowThreads) want = kRowThreads;
     if (want < 1 || height < 64) want = 1;
     if (want == 1) {
         fn(0, 0, height);
@@ -461,9 +463,9 @@ template <typename F> void for_row_blocks(int height, F fn) {
 // changes), so rows are split over threads; the bytes are those of the sequential loops.
 extern "C" int pth_tonemap_rgb8(const float *linear_rgb, int width, int height, uint8_t *rgb8) {
     const pt_vec3 *px = (const pt_vec3 *)linear_rgb;
-    float whites[16];
-    long long bad[16];
-    for (int t = 0; t < 16; t++) {
+    float whites[kRowThreads];
+    long long bad[kRowThreads];
+    for (int t = 0; t < kRowThreads; t++) {
         whites[t] = luminance(v3(1, 1, 1));
         bad[t] = -1;
     }
@@ -482,7 +484,7 @@ extern "C" int pth_tonemap_rgb8(const float *linear_rgb, int width, int height, 
     });
     long long first_bad = -1;
     float white = luminance(v3(1, 1, 1));
-    for (int t = 0; t < 16; t++) {
+    for (int t = 0; t < kRowThreads; t++) {
         if (bad[t] >= 0 && (first_bad < 0 || bad[t] < first_bad)) first_bad = bad[t];
         white = fmaxf(white, whites[t]);
     }
@@ -674,7 +676,7 @@ extern "C" int pth_write_png_rgb8(const uint8_t *rgb8, int width, int height, co
             n -= m;
         }
     };
-    Adler sums[16];
+    Adler sums[kRowThreads];
     for_row_blocks(height, [&](int t, int y0, int y1) {
         Adler s;
         s.a = 0; // a block's own sums start from (0, 0): the leading 1 belongs to the whole stream
@@ -690,7 +692,7 @@ extern "C" int pth_write_png_rgb8(const uint8_t *rgb8, int width, int height, co
         sums[t] = s;
     });
     Adler total; // (1, 0, 0)
-    for (int t = 0; t < 16; t++)
+    for (int t = 0; t < kRowThreads; t++)
         if (sums[t].len) { // adler_concat expects finished values: a block that started from 0 has a one short
             Adler y = sums[t];
             y.a = (y.a + 1) % kAdlerMod;
@@ -703,21 +705,17 @@ extern "C" int pth_write_png_rgb8(const uint8_t *rgb8, int width, int height, co
     memcpy(file.data() + idat_at + 4, "IDAT", 4);
     const uint8_t *body = file.data() + idat_at + 4;
     const size_t body_len = 4 + z_len;
-    uint32_t piece_crc[16];
-    size_t piece_len[16] = {0};
-    const int pieces = body_len >= (1u << 20) ? 16 : 1;
-    for_row_blocks(pieces >= 16 ? 1024 : 1, [&](int t, int p0, int p1) { // 1024 slots shared out over the threads
-        size_t lo = body_len * (size_t)p0 / 1024, hi = body_len * (size_t)p1 / 1024;
-        if (pieces == 1) {
-            lo = 0;
-            hi = body_len;
-        }
+    uint32_t piece_crc[kRowThreads];
+    size_t piece_len[kRowThreads] = {0};
+    const bool split = body_len >= (1u << 20); // below a megabyte one thread is faster than starting several
+    for_row_blocks(split ? 1024 : 1, [&](int t, int p0, int p1) { // 1024 slots of the body shared out over the threads
+        size_t lo = split ? body_len * (size_t)p0 / 1024 : 0, hi = split ? body_len * (size_t)p1 / 1024 : body_len;
         piece_crc[t] = crc32_of(body + lo, hi - lo);
         piece_len[t] = hi - lo;
     });
     uint32_t crc = 0;
     bool first = true;
-    for (int t = 0; t < 16; t++) {
+    for (int t = 0; t < kRowThreads; t++) {
         if (!piece_len[t]) continue;
         crc = first ? piece_crc[t] : crc32_concat(crc, piece_crc[t], piece_len[t]);
         first = false;

@@ -8,7 +8,8 @@ The exact variant stays the gate (every other GPU test); this file states what t
 Measured on the box (round 3, profiles/r03_tolerance.log):
   * ids, jittered rays (what a render traces): cornell 256^2 1 of 65 536, dragon 1024^2 16 of 1 048 576, glass_mirror
     1024^2 0, a grid of 180 000 tiny triangles 22; without jitter the pixel grid meets the axis-aligned meshes EXACTLY on
-    their edges, where exact arithmetic gives u == 0 in both neighbours and a fused one +-1e-9: 62 / 18 / 131 / 224.
+    their edges, where exact arithmetic gives u == 0 in both neighbours and a fused one +-1e-9: 62 / 18 / 131 / 727 (224 on the grid in an earlier build: which products
+    the compiler fuses changes with the surrounding code, and these rays sit exactly on the edges).
   * image: a path only changes when a differently rounded number flips a DECISION (rejection test, Russian roulette,
     an edge), which a 1e-7 relative change rarely does; otherwise the pixel differs in its last bits. C1 (cornell
     256^2 x 16 spp): per-pixel RMSE 7e-8 = 1e-6 of the image mean, mean relative error 1e-8, against an RMSE of 0.094

@@ -787,8 +787,9 @@ def test_png_writer_checksums_and_stored_blocks_against_zlib(tmp_path, monkeypat
     lib = _ffi.host_lib()
     rng = np.random.default_rng(3)
     path = str(tmp_path / "t.png")
-    for (w, h) in [(1, 1), (7, 5), (300, 200), (21845, 1), (3, 21846), (1000, 1100), (1024, 1024)]:
-        for threads in ("1", "16"):
+    # (1, 65535): the raw stream is exactly four blocks; (5461, 4), (10922, 2): one byte over / under a block
+    for (w, h) in [(1, 1), (7, 5), (300, 200), (21845, 1), (3, 21846), (1, 65535), (5461, 4), (10922, 2), (1000, 1100), (1024, 1024)]:
+        for threads in ("1", "7", "16"):
             monkeypatch.setenv("PTH_BUILD_THREADS", threads)
             img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
             assert lib.pth_write_png_rgb8(img.ctypes.data_as(C.c_void_p), w, h, path.encode()) == 0
